@@ -1,0 +1,92 @@
+"""Pin the CPU oracle against outputs of the real reference (tests/golden/*.npz,
+made by tests/golden/make_golden.py).  fp32 on both sides, same torch build, so
+the tolerance is fp32 reassociation noise only."""
+import numpy as np
+import torch
+
+from conftest import TINY_UNET_CFG, load_golden, rel_l2, sub_state_dict
+from oracle import decoder as odec
+from oracle import sampler as osamp
+from oracle import unet as ounet
+
+
+def test_schedule_buffers_bit_exact():
+    g = load_golden("schedule.npz")
+    b = osamp.make_schedule_buffers()
+    for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
+              "sqrt_one_minus_alphas_cumprod", "scale_arr"):
+        assert np.array_equal(b[k].numpy(), g[k]), k
+    assert b["scale_arr"].shape[0] == 1400            # 400 + 1000 entries
+    # known answers recorded in SURVEY.md 8c
+    ac = b["alphas_cumprod"].numpy()
+    np.testing.assert_allclose(ac[[0, 1, 499, 998, 999]],
+                               [0.99915, 0.998233446, 0.242359167, 1.96788806e-07, 0.0], rtol=2e-7, atol=0)
+
+
+def test_ddim_tables_bit_exact():
+    g = load_golden("schedule.npz")
+    b = osamp.make_schedule_buffers()
+    for tag, S, eta, method in (("s50_trailing", 50, 1.0, "uniform_trailing"),
+                                ("s2_trailing", 2, 1.0, "uniform_trailing"),
+                                ("s50_uniform", 50, 0.0, "uniform"),
+                                ("s5_trailing", 5, 1.0, "uniform_trailing")):
+        t = osamp.make_ddim_tables(b, S, eta, method)
+        assert np.array_equal(np.asarray(t["timesteps"]), g[tag + "_timesteps"]), tag
+        assert np.array_equal(np.asarray(t["alphas"], dtype=np.float64), g[tag + "_alphas"]), tag
+        assert np.array_equal(np.asarray(t["alphas_prev"], dtype=np.float64), g[tag + "_alphas_prev"]), tag
+        assert np.array_equal(np.asarray(t["sigmas"], dtype=np.float64), g[tag + "_sigmas"]), tag
+        assert np.array_equal(t["scale_arr"].numpy(), g[tag + "_scale_arr"]), tag
+        assert np.array_equal(t["scale_arr_prev"].numpy(), g[tag + "_scale_arr_prev"]), tag
+    t = osamp.make_ddim_tables(b, 50, 1.0, "uniform_trailing")
+    assert list(t["timesteps"][:3]) == [19, 39, 59] and t["timesteps"][-1] == 999
+    np.testing.assert_allclose(np.asarray(t["sigmas"])[[0, 1, 49]], [0.02850725, 0.10053112, 0.99995711], rtol=1e-6)
+    # first DDIM step is singular (zero terminal SNR): radicand must be the tiny POSITIVE fp32 value
+    rad = g["s50_trailing_radicand_f32"]
+    assert rad[49] > 0 and abs(rad[49] - 5.9604645e-08) < 1e-12
+
+
+def test_unet_tiny_matches_reference(tiny_sd):
+    g = load_golden("unet_tiny.npz")
+    sd = sub_state_dict(tiny_sd, "model.diffusion_model.")
+    assert sum(v.numel() for v in sd.values()) == int(g["n_params"])
+    y = ounet.unet_forward(sd, TINY_UNET_CFG, torch.from_numpy(g["x"]), torch.from_numpy(g["timesteps"]),
+                           torch.from_numpy(g["context"]), torch.from_numpy(g["fs"]))
+    ref = torch.from_numpy(g["y"])
+    assert y.shape == ref.shape
+    assert rel_l2(y, ref) < 2e-5, rel_l2(y, ref)
+
+
+def test_decoder_tiny_matches_reference(tiny_sd):
+    g = load_golden("decoder_tiny.npz")
+    sd = sub_state_dict(tiny_sd, "first_stage_model.decoder.")
+    assert sum(v.numel() for v in sd.values()) == int(g["n_params"])
+    refs = [torch.from_numpy(g[f"ref{i}"]) for i in range(5)]
+    z = torch.from_numpy(g["z"])
+    out = odec.decode_first_stage(sd, z, refs)
+    ref = torch.from_numpy(g["dec_first_stage"])
+    assert out.shape == ref.shape
+    assert rel_l2(out, ref) < 2e-5, rel_l2(out, ref)
+    # module-level entry (frames-major) agrees with the pipeline-level one
+    dec = torch.from_numpy(g["dec"])
+    assert rel_l2(out[0].permute(1, 0, 2, 3), dec) < 2e-5
+
+
+def test_ddim_tiny_trajectory_matches_reference(tiny_sd):
+    g = load_golden("ddim_tiny.npz")
+    sd = sub_state_dict(tiny_sd, "model.diffusion_model.")
+    bufs = osamp.make_schedule_buffers()
+    c_concat = torch.from_numpy(g["c_concat"])
+    fs = torch.from_numpy(g["fs"])
+
+    def apply_model(x, t, ctx):      # ddpm3d.py:735-750 + DiffusionWrapper hybrid (1260-1264)
+        return ounet.unet_forward(sd, TINY_UNET_CFG, torch.cat([x, c_concat], dim=1), t, ctx, fs)
+
+    noises = torch.from_numpy(g["noises"])
+    x0s = []
+    out = osamp.ddim_sample(apply_model, torch.from_numpy(g["x_T"]), torch.from_numpy(g["cond"]),
+                            torch.from_numpy(g["uncond"]), S=5, eta=1.0, cfg_scale=7.5, guidance_rescale=0.7,
+                            buffers=bufs, noise_fn=lambda i: noises[i],
+                            step_callback=lambda i, img, p: x0s.append(p))
+    for i, p in enumerate(x0s):
+        assert rel_l2(p, torch.from_numpy(g["pred_x0"][i])) < 1e-4, i
+    assert rel_l2(out, torch.from_numpy(g["samples"])) < 1e-4
