@@ -1,0 +1,181 @@
+/*
+ * tooncrafter_hip.h -- C ABI of the MI355X (gfx950) kernels behind the ToonCrafter
+ * denoising hot path (DDIM sampler -> spatio-temporal UNet -> dual-reference
+ * VideoDecoder).
+ *
+ * The reference (Doubiiu/ToonCrafter) is pure PyTorch: it has no FFI of its own.
+ * What it binds instead are third-party kernels (ATen conv/GEMM/norm/softmax,
+ * xformers.memory_efficient_attention).  Every entry point below replaces one of
+ * those call sites; the reference file:line is given with each.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers to DEVICE memory, sizes as int/int64, no torch types;
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it;
+ *   - never allocates, never synchronises, hipGraph-capture safe;
+ *   - returns 0 on success, a negative TC_E* code on a bad argument (nothing launched),
+ *     or the positive hipError_t of a failed launch;
+ *   - activations are bf16 "channels-last rows": a tensor (B,T,H,W,C) is a row-major
+ *     matrix [B*T*H*W, C]; weights are bf16 [N, K] row-major (K contiguous).
+ */
+#ifndef TOONCRAFTER_HIP_H
+#define TOONCRAFTER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TC_ABI_VERSION 1
+
+enum {
+  TC_OK = 0,
+  TC_EINVAL = -1,      /* null pointer / non-positive size */
+  TC_EALIGN = -2,      /* pointer or leading dimension not 16-byte aligned */
+  TC_ESHAPE = -3,      /* shape outside what the kernel supports */
+  TC_EWORKSPACE = -4   /* workspace too small */
+};
+
+typedef uint16_t tc_bf16;   /* raw bfloat16 bits */
+
+/* ---- activation applied in the GEMM epilogue ---- */
+enum { TC_ACT_NONE = 0, TC_ACT_SILU = 1, TC_ACT_GELU = 2, TC_ACT_GEGLU = 3 };
+
+/* ---- how GEMM rows of A are gathered (implicit-GEMM convolution) ---- */
+enum {
+  TC_GATHER_LINEAR = 0,   /* A[m, k] = a[m*lda + k]                                  (nn.Linear, 1x1 conv) */
+  TC_GATHER_CONV3x3 = 1,  /* 3x3, pad 1, stride `stride`, optional nearest-x2 source  (nn.Conv2d)           */
+  TC_GATHER_CONVT3 = 2    /* (3,1,1) over T, pad (1,0,0)                              (nn.Conv3d)           */
+};
+
+typedef struct TcGemmParams {
+  /* operands */
+  const tc_bf16* a;        /* activations, channels-last rows */
+  const tc_bf16* w;        /* [N, K] bf16; K = taps*cin, tap-major then channel; for TC_ACT_GEGLU
+                              rows are packed per 128-row block: 64 value rows then their 64 gate rows */
+  void* c;                 /* [M, ldc] bf16 (or fp32 when out_f32) */
+  const float* bias;       /* [N] fp32 or NULL (same packing as w rows) */
+  const float* row_bias;   /* [ceil(M/row_div), N] fp32 or NULL: per-frame embedding add */
+  const tc_bf16* residual; /* [M, ldr] bf16 or NULL, added last */
+  /* sizes */
+  int32_t m, n, k;         /* n, k as stored in w; with GEGLU the output has n/2 columns */
+  int32_t lda, ldw, ldc, ldr; /* leading dimensions in elements (multiples of 8); ldw >= k */
+  int32_t ldrb;            /* leading dimension of row_bias (>= n) */
+  int32_t row_div;         /* rows sharing one row_bias row (H*W) */
+  /* epilogue:  v = act(alpha*acc + bias + row_bias) * out_scale + residual */
+  float alpha, out_scale;
+  int32_t act;
+  int32_t out_f32;
+  /* gather geometry */
+  int32_t gather;
+  int32_t cin;             /* channels per tap (multiple of 64 when taps > 1) */
+  int32_t frames;          /* B*T images */
+  int32_t t_len;           /* T, frames per clip (CONVT3 bounds) */
+  int32_t h_out, w_out;    /* output image size: m = (frame*h_out + y)*w_out + x */
+  int32_t h_in, w_in;      /* source image size */
+  int32_t stride;          /* 1 or 2 */
+  int32_t upsample;        /* 1: source is nearest-upsampled x2 on the fly (Upsample + conv fused) */
+  /* batching (blockIdx.z): element strides, 0 = shared */
+  int32_t batch;
+  int64_t stride_a, stride_w, stride_c;
+} TcGemmParams;
+
+/* C = epilogue(gather(A) * W^T), bf16 MFMA, fp32 accumulate.
+ * Replaces: nn.Linear (lvdm/modules/attention.py:53-57,75-76,269,290,336,362,418,438;
+ * openaimodel3d.py:170,371-380), nn.Conv2d 3x3/1x1 (openaimodel3d.py:68-70,96,154,179,187,386,545;
+ * autoencoder_dualref.py:52-68,419-462,921-927), nn.Conv3d (3,1,1) (openaimodel3d.py:255-266;
+ * autoencoder_dualref.py:601-605,641-648), F.interpolate nearest x2 (openaimodel3d.py:98-106),
+ * GEGLU (attention.py:420-422) and the residual/embedding adds around them. */
+int tc_gemm_bf16(const TcGemmParams* p, void* stream);
+
+typedef struct TcAttnParams {
+  const tc_bf16* q; const tc_bf16* k; const tc_bf16* v; tc_bf16* o;
+  int32_t batch, heads, lq, lk;
+  /* element (b, h, i, d) lives at ptr + b*sb + i*ss + h*64 + d  (head dim 64, contiguous) */
+  int64_t q_sb, k_sb, v_sb, o_sb;
+  int32_t q_ss, k_ss, v_ss, o_ss;
+  int32_t kv_bdiv;     /* K/V batch index = b / kv_bdiv (shared reference / text keys) */
+  int32_t accumulate;  /* 1: o += result (second softmax of the image cross-attention) */
+  float scale;         /* d^-0.5 */
+} TcAttnParams;
+
+/* softmax(q k^T * scale) v, head dim 64, flash-style (scores never leave the CU).
+ * Replaces xformers.ops.memory_efficient_attention at lvdm/modules/attention.py:175,187 and
+ * lvdm/models/autoencoder_dualref.py:316,326 (and the einsum fallback attention.py:103-134). */
+int tc_attn_d64(const TcAttnParams* p, void* stream);
+
+/* Temporal self-attention over <=16 frames at every pixel (attention.py:81-144 via
+ * TemporalTransformer, attention.py:365-412).  qkv: fused [rows, 3*C] projection with
+ * row = (b*T + t)*HW + p; columns [0,C)=q, [C,2C)=k, [2C,3C)=v, head h at h*64.
+ * out: [rows, C] bf16. */
+int tc_attn_temporal(const tc_bf16* qkv, tc_bf16* out, int32_t b, int32_t t, int32_t hw,
+                     int32_t heads, float scale, void* stream);
+
+/* GroupNorm(32 groups) over channels-last rows, fp32 statistics, optional fused SiLU.
+ * x: [samples, rows, C]; statistics over (rows, C/32) per (sample, group): samples = B*T,
+ * rows = H*W for the per-frame norms; samples = B, rows = T*H*W for the clip-wide ones.
+ * Replaces GroupNormSpecific / nn.GroupNorm + nn.SiLU (lvdm/basics.py:76-87;
+ * openaimodel3d.py:152-153,176-177,256-265; attention.py:265,331; autoencoder_dualref.py:29-32).
+ * workspace: tc_groupnorm_workspace() bytes of fp32 partial sums. */
+int64_t tc_groupnorm_workspace(int32_t samples, int32_t rows, int32_t c);
+int tc_groupnorm(const tc_bf16* x, tc_bf16* y, const float* gamma, const float* beta,
+                 int32_t samples, int32_t rows, int32_t c, float eps, int32_t silu,
+                 void* workspace, int64_t workspace_bytes, void* stream);
+
+/* LayerNorm over the last axis of [rows, C] (attention.py:225-227), eps 1e-5, affine. */
+int tc_layernorm(const tc_bf16* x, tc_bf16* y, const float* gamma, const float* beta,
+                 int32_t rows, int32_t c, float eps, void* stream);
+
+/* Row softmax fp32 [rows, n] -> bf16 [rows, ldo] (single-head d=512 mid attention of the
+ * decoder, autoencoder_dualref.py:172-200, computed as GEMM + softmax + GEMM). */
+int tc_softmax_rows(const float* s, tc_bf16* p, int32_t rows, int32_t n, int32_t lds, int32_t ldo,
+                    void* stream);
+
+/* (B, C, T, H, W) fp32, optionally two tensors concatenated on C, -> channels-last bf16
+ * [B*T*H*W, c_pad] zero padded, times `scale`.  The hybrid-conditioning concat of
+ * ddpm3d.py:1260-1264 and the `b c t h w -> (b t) c h w` rearranges (openaimodel3d.py:566). */
+int tc_nchw_to_rows(const float* x0, int32_t c0, const float* x1, int32_t c1, tc_bf16* out,
+                    int32_t c_pad, int32_t b, int32_t t, int32_t hw, float scale, void* stream);
+/* rows -> (B, C, T, H, W) fp32: the inverse rearrange (openaimodel3d.py:602). src may be bf16 or fp32. */
+int tc_rows_to_nchw(const void* src, int32_t src_f32, int32_t ld, float* out, int32_t c,
+                    int32_t b, int32_t t, int32_t hw, void* stream);
+/* Channel concat of two rows tensors [rows, ca] | [rows, cb] -> [rows, ca+cb]: the UNet skip
+ * connections (openaimodel3d.py:596). */
+int tc_concat_rows(const tc_bf16* a, int32_t ca, const tc_bf16* b, int32_t cb, tc_bf16* out,
+                   int64_t rows, void* stream);
+
+/* Sinusoidal embedding [cos | sin] (utils_diffusion.py:19-23) -> bf16 [n, dim_pad], then optional SiLU elementwise helper. */
+int tc_timestep_embedding(const float* t, tc_bf16* out, int32_t n, int32_t dim, int32_t ld, void* stream);
+int tc_silu_f32_to_bf16(const float* x, tc_bf16* y, int64_t n, void* stream);
+
+/* AE3DConv tail (autoencoder_dualref.py:929-935): Conv3d 3->3 (3,1,1) over T on the fp32
+ * [B*T*HW, ld] rows produced by the 128->3 conv, written as (B, 3, T, H, W) fp32. */
+int tc_time_mix3(const float* rows, int32_t ld, const float* w, const float* bias, float* out,
+                 int32_t b, int32_t t, int32_t hw, void* stream);
+
+typedef struct TcDdimParams {
+  const float* x;        /* current latent (B, n) fp32 */
+  const float* e_cond;   /* UNet output for the conditional pass (B, n) */
+  const float* e_uncond; /* unconditional pass, or NULL */
+  const float* noise;    /* N(0,1) draw or NULL (sigma == 0) */
+  float* x_prev; float* pred_x0;
+  int32_t b; int64_t n;  /* n = C*T*H*W */
+  float cfg_scale, guidance_rescale;
+  /* fp32 scalars in the reference's order of operations (ddim.py:251-277, ddpm3d.py:240-252) */
+  float sqrt_ac, sqrt_1m_ac, sqrt_a_prev, dir_coef /* sqrt(1-a_prev-sigma^2) */, sigma, x0_rescale;
+} TcDdimParams;
+
+/* CFG combine + rescale_noise_cfg (unbiased std over each sample) + v->(eps,x0) + dynamic
+ * rescale + x_prev, fused.  Replaces ddim.py:226-277 and utils_diffusion.py:147-158.
+ * workspace: b * 64 * 4 doubles. */
+int64_t tc_ddim_workspace(int32_t b);
+int tc_ddim_step(const TcDdimParams* p, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* introspection */
+int tc_abi_version(void);
+const char* tc_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOONCRAFTER_HIP_H */

@@ -53,7 +53,7 @@ TINY_UNET_CFG = dict(in_channels=8, out_channels=4, model_channels=64, num_res_b
                      use_causal_attention=False, temporal_length=4, addition_attention=True,
                      image_cross_attention=True, default_fs=24, fs_condition=True, dropout=0.1,
                      use_checkpoint=False)
-TINY_DD_CFG = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=32,
+TINY_DD_CFG = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=64,
                    ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0)
 FULL_UNET_CFG = dict(TINY_UNET_CFG, model_channels=320, context_dim=1024, temporal_length=16)
 FULL_DD_CFG = dict(TINY_DD_CFG, ch=128)

@@ -1,0 +1,194 @@
+"""CPU emulation of the operator contract of tooncrafter_amd.ops.HipOps.
+
+TEST DOUBLE ONLY (lives under tests/, never imported by the product).  It states,
+in plain PyTorch, what each `tc_*` entry point must compute -- bf16 storage, fp32
+arithmetic -- so that (a) the host logic of the module mirror (layouts, weight
+packing, state-dict mapping, sampler scalars) can be validated against the oracle
+and the reference goldens without a GPU, and (b) the GPU tests have a per-operator
+specification to check the HIP kernels against.
+"""
+import torch
+import torch.nn.functional as F
+
+from tooncrafter_amd._lib import ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_SILU
+
+BF16 = torch.bfloat16
+
+
+def _f(t):
+    return t.to(torch.float32)
+
+
+class EmuOps:
+    name = "emu"
+
+    def __init__(self, round_bf16=True):
+        self.round = round_bf16
+
+    def _out(self, x, f32=False):
+        if f32:
+            return x.to(torch.float32)
+        return x.to(BF16) if self.round else x
+
+    # ------------------------------------------------------------------ GEMM family
+    def _gather(self, a, conv, k):
+        if conv is None:
+            return _f(a[:, :k])
+        fr, cin = conv["frames"], conv["cin"]
+        ho, wo = conv["h_out"], conv["w_out"]
+        if conv["kind"] == "3x3":
+            hi, wi = conv.get("h_in", ho), conv.get("w_in", wo)
+            x = _f(a[:fr * hi * wi, :cin]).reshape(fr, hi, wi, cin).permute(0, 3, 1, 2)
+            if conv.get("upsample", False):
+                x = F.interpolate(x, scale_factor=2, mode="nearest")
+            cols = F.unfold(x, kernel_size=3, padding=1, stride=conv.get("stride", 1))   # [fr, cin*9, L]
+            cols = cols.reshape(fr, cin, 9, ho * wo).permute(0, 3, 2, 1)                 # [fr, L, tap, cin]
+            return cols.reshape(fr * ho * wo, 9 * cin)
+        t = conv["t_len"]
+        hw = ho * wo
+        x = _f(a[:fr * hw, :cin]).reshape(fr // t, t, hw, cin)
+        xp = F.pad(x, (0, 0, 0, 0, 1, 1))
+        cols = torch.stack([xp[:, 0:t], xp[:, 1:t + 1], xp[:, 2:t + 2]], dim=3)           # [b, t, hw, tap, cin]
+        return cols.reshape(fr * hw, 3 * cin)
+
+    def gemm(self, a, w, bias=None, *, act=ACT_NONE, residual=None, row_bias=None, row_div=0, alpha=1.0,
+             out_scale=1.0, out=None, out_f32=False, conv=None, batch=1, stride_a=0, stride_w=0, stride_c=0,
+             m=None):
+        n, k = w.shape
+        if batch > 1:
+            assert conv is None and residual is None and row_bias is None
+            mm = a.shape[0]
+            res = []
+            for i in range(batch):
+                ai = torch.as_strided(a, a.shape, a.stride(), a.storage_offset() + i * stride_a)
+                wi = torch.as_strided(w, w.shape, w.stride(), w.storage_offset() + i * stride_w)
+                oi = torch.as_strided(out, out.shape, out.stride(), out.storage_offset() + i * stride_c)
+                self.gemm(ai, wi, bias, act=act, alpha=alpha, out_scale=out_scale, out=oi, out_f32=out_f32)
+            return out
+        A = self._gather(a, conv, k)
+        if m is not None:
+            A = A[:m]
+        acc = (A @ _f(w).t()) * alpha
+        if act == ACT_GEGLU:
+            # rows packed per 128: [64 values | 64 gates]
+            nb = n // 128
+            acc = acc.reshape(-1, nb, 2, 64)
+            if bias is not None:
+                acc = acc + bias.reshape(nb, 2, 64)
+            v = acc[:, :, 0] * F.gelu(acc[:, :, 1])
+            v = v.reshape(-1, nb * 64) * out_scale
+        else:
+            if bias is not None:
+                acc = acc + bias
+            if row_bias is not None:
+                idx = torch.arange(acc.shape[0], device=acc.device) // row_div
+                acc = acc + row_bias[idx]
+            if act == ACT_SILU:
+                acc = F.silu(acc)
+            elif act == ACT_GELU:
+                acc = F.gelu(acc)
+            v = acc * out_scale
+        if residual is not None:
+            v = v + _f(residual[:v.shape[0]])
+        res = self._out(v, out_f32)
+        if out is not None:
+            out[:v.shape[0]].copy_(res)
+            return out
+        return res.contiguous()
+
+    # ------------------------------------------------------------------ attention
+    def attention(self, q, k, v, *, batch, heads, lq, lk, kv_bdiv=1, out=None, accumulate=False, scale=None):
+        scale = 64 ** -0.5 if scale is None else scale
+        qf = _f(q).reshape(batch, lq, heads, 64).permute(0, 2, 1, 3)
+        kvb = (batch + kv_bdiv - 1) // kv_bdiv
+        kf = _f(k).reshape(kvb, lk, heads, 64).permute(0, 2, 1, 3)
+        vf = _f(v).reshape(kvb, lk, heads, 64).permute(0, 2, 1, 3)
+        idx = (torch.arange(batch) // kv_bdiv).tolist()
+        outs = []
+        for i in range(batch):
+            s = (qf[i] @ kf[idx[i]].transpose(-1, -2)) * scale
+            outs.append(s.softmax(-1) @ vf[idx[i]])
+        o = torch.stack(outs).permute(0, 2, 1, 3).reshape(batch * lq, heads * 64)
+        if accumulate:
+            o = o + _f(out)
+        o = self._out(o)
+        if out is not None:
+            out.copy_(o)
+            return out
+        return o.contiguous()
+
+    def attention_temporal(self, qkv, *, b, t, hw, heads, scale=None):
+        scale = 64 ** -0.5 if scale is None else scale
+        c = heads * 64
+        x = _f(qkv).reshape(b, t, hw, 3, heads, 64)
+        q, k, v = (x[:, :, :, i].permute(0, 2, 3, 1, 4) for i in range(3))    # [b, hw, heads, t, 64]
+        s = (q @ k.transpose(-1, -2)) * scale
+        o = s.softmax(-1) @ v
+        return self._out(o.permute(0, 3, 1, 2, 4).reshape(b * t * hw, c)).contiguous()
+
+    # ------------------------------------------------------------------ norms
+    def groupnorm(self, x, gamma, beta, *, samples, rows, eps, silu=False):
+        c = x.shape[1]
+        xf = _f(x).reshape(samples, rows, c).permute(0, 2, 1)
+        y = F.group_norm(xf, 32, gamma, beta, eps)
+        if silu:
+            y = F.silu(y)
+        return self._out(y.permute(0, 2, 1).reshape(samples * rows, c)).contiguous()
+
+    def layernorm(self, x, gamma, beta, eps=1e-5):
+        return self._out(F.layer_norm(_f(x), (x.shape[1],), gamma, beta, eps))
+
+    def softmax_rows(self, s):
+        return self._out(s.softmax(-1))
+
+    # ------------------------------------------------------------------ layout / elementwise
+    def nchw_to_rows(self, x0, x1=None, *, c_pad, scale=1.0):
+        x = x0 if x1 is None else torch.cat([x0, x1], dim=1)
+        b, c, t, h, w = x.shape
+        rows = (x * scale).permute(0, 2, 3, 4, 1).reshape(b * t * h * w, c)
+        out = torch.zeros((rows.shape[0], c_pad), dtype=torch.float32, device=x.device)
+        out[:, :c] = rows
+        return out.to(BF16)
+
+    def rows_to_nchw(self, rows, *, c, b, t, h, w):
+        return _f(rows[:, :c]).reshape(b, t, h, w, c).permute(0, 4, 1, 2, 3).contiguous()
+
+    def concat_rows(self, a, b):
+        return torch.cat([a, b], dim=1).contiguous()
+
+    def timestep_embedding(self, t, dim, ld=None):
+        import math
+        ld = dim if ld is None else ld
+        half = dim // 2
+        freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
+        args = t[:, None].float() * freqs[None]
+        out = torch.zeros((t.shape[0], ld), dtype=torch.float32, device=t.device)
+        out[:, :half] = torch.cos(args)
+        out[:, half:2 * half] = torch.sin(args)
+        return out.to(BF16)
+
+    def silu_to_bf16(self, x):
+        return F.silu(x).to(BF16)
+
+    def time_mix3(self, rows, w, bias, *, b, t, h, w_):
+        x = rows[:, :3].reshape(b, t, h, w_, 3).permute(0, 4, 1, 2, 3)
+        return F.conv3d(x, w.reshape(3, 3, 3, 1, 1), bias, padding=(1, 0, 0)).contiguous()
+
+    def ddim_step(self, x, e_cond, e_uncond, noise, *, cfg_scale, guidance_rescale, sqrt_ac, sqrt_1m_ac,
+                  sqrt_a_prev, dir_coef, sigma, x0_rescale, want_x0=True):
+        f = lambda v: torch.tensor(v, dtype=torch.float32, device=x.device)
+        v = e_cond
+        if e_uncond is not None:
+            v = e_uncond + cfg_scale * (e_cond - e_uncond)
+            if guidance_rescale > 0:
+                dims = list(range(1, v.dim()))
+                st = e_cond.double().std(dim=dims, keepdim=True)
+                sc = v.double().std(dim=dims, keepdim=True)
+                fac = (st / sc).float()
+                v = guidance_rescale * (v * fac) + (1 - guidance_rescale) * v
+        e_t = f(sqrt_ac) * v + f(sqrt_1m_ac) * x
+        x0 = (f(sqrt_ac) * x - f(sqrt_1m_ac) * v) * f(x0_rescale)
+        xp = f(sqrt_a_prev) * x0 + f(dir_coef) * e_t
+        if noise is not None:
+            xp = xp + f(sigma) * noise
+        return xp, (x0 if want_x0 else None)

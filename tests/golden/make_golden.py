@@ -13,7 +13,7 @@ script only calls its public classes and saves input/output tensors:
   schedule.npz       DDPM.register_schedule buffers + DDIMSampler.make_schedule tables
                      for the full 1000-step config (S=50 eta=1 trailing, S=2, S=50 uniform)
   unet_tiny.npz      UNetModel forward, 64-channel config, T=4, 8x8 latent
-  decoder_tiny.npz   VideoDecoder forward via AutoencoderKL_Dualref.decode, ch=32, T=3
+  decoder_tiny.npz   VideoDecoder forward via AutoencoderKL_Dualref.decode, ch=64, T=3
   ddim_tiny.npz      5-step DDIM trajectory (CFG 7.5, rescale 0.7, eta=1, injected noise)
                      through LatentVisualDiffusion.apply_model, then decode_first_stage
 
@@ -103,7 +103,7 @@ def tiny_config():
     u["temporal_length"] = 4
     u["use_checkpoint"] = False
     d = p["first_stage_config"]["params"]["ddconfig"]
-    d["ch"] = 32
+    d["ch"] = 64
     p["cond_stage_config"] = {"target": "torch.nn.Identity"}
     p["img_cond_stage_config"] = {"target": "torch.nn.Identity"}
     p["image_proj_stage_config"] = {"target": "torch.nn.Identity"}
@@ -204,7 +204,7 @@ def main():
     Td, hd, wd = 3, 4, 6
     g = torch.Generator().manual_seed(21)
     z = torch.randn(1, 4, Td, hd, wd, generator=g)
-    ref_ctx = synth.synth_ref_context(1, hd, wd, ch=32, seed=11)
+    ref_ctx = synth.synth_ref_context(1, hd, wd, ch=64, seed=11)
     dec_in = (1.0 / 0.18215) * z.permute(0, 2, 1, 3, 4).reshape(Td, 4, hd, wd)
     dec = model.first_stage_model.decode(dec_in, ref_context=ref_ctx, timesteps=Td)
     # and through the pipeline-level entry point (z * 1/scale_factor inside)

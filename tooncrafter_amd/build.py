@@ -1,0 +1,73 @@
+"""Build the gfx950 shared library in-tree with hipcc (cross-compiles without a GPU).
+
+    python -m tooncrafter_amd.build          # -> tooncrafter_amd/libtooncrafter_hip.so
+
+The .so is git-ignored but travels to the GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libtooncrafter_hip.so")
+SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "elementwise.hip"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "tooncrafter_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on",
+         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: the HIP library cannot be built")
+
+
+def _digest() -> str:
+    h = hashlib.sha256()
+    for p in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    stamp = LIB + ".stamp"
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return LIB
+    hipcc = _hipcc()
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    procs = []
+    objs = []
+    for s in SOURCES:
+        o = os.path.join(objdir, s.replace(".hip", ".o"))
+        objs.append(o)
+        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, s), "-o", o]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for s, pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            sys.stderr.write(out.decode(errors="replace"))
+            raise RuntimeError(f"hipcc failed on {s}")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    if verbose:
+        print("[build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(dig)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,285 @@
+// Attention kernels, head dim 64, gfx950.
+//
+// attn_d64_kernel: flash-style softmax(q k^T * scale) v.  One block = 128 query rows of one
+// (batch, head): 4 waves x 32 rows.  Per 64-key tile the block stages K row-major and V
+// TRANSPOSED ([d][key]) in LDS; each wave then computes S^T = K Q^T with
+// v_mfma_f32_32x32x16_bf16 ("swapped" product: every lane owns ONE query column, so the
+// softmax row reductions are in-lane plus a single lane^32 exchange), exponentiates in
+// registers, and feeds the probabilities straight back as the B operand of
+// O^T += V^T P^T -- the accumulator-to-operand key permutation is absorbed by reading the
+// V^T fragments with the same permutation, so P never touches LDS.
+//
+// attn_temporal_kernel: 16-frame (or shorter) self-attention at every pixel; the whole
+// problem is 16x16x64 per (pixel, head), done on the VALU by one wave.
+#include "common.h"
+
+namespace {
+
+constexpr int KT = 64;            // keys per tile
+constexpr int K_STRIDE = 144;     // bytes per K row in LDS (128 + 16 pad): conflict-free ds_read_b128
+constexpr int VT_STRIDE = 136;    // bytes per V^T row (64 keys * 2 + 8 pad): conflict-free ds_read_b64
+constexpr int K_BYTES = KT * K_STRIDE;     // 9216
+constexpr int VT_BYTES = 64 * VT_STRIDE;   // 8704
+
+__global__ __launch_bounds__(256) void attn_d64_kernel(const TcAttnParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[K_BYTES + VT_BYTES];
+  char* ks = smem;
+  char* vts = smem + K_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int kvb = b / p.kv_bdiv;
+  const bf16_t* qb = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.q_sb + h * 64;
+  const bf16_t* kb = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)kvb * p.k_sb + h * 64;
+  const bf16_t* vb = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)kvb * p.v_sb + h * 64;
+  bf16_t* ob = reinterpret_cast<bf16_t*>(p.o) + (int64_t)b * p.o_sb + h * 64;
+
+  const int q_row = blockIdx.x * 128 + wave * 32 + l31;
+  const int q_ld = q_row < p.lq ? q_row : p.lq - 1;   // clamp: tail rows compute garbage, never stored
+
+  // Q fragments: B operand of S^T = K Q^T -> lane holds Q[q][16 kk + 8 half + j]
+  bf16x8 qf[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+    qf[kk] = *reinterpret_cast<const bf16x8*>(qb + (int64_t)q_ld * p.q_ss + kk * 16 + half * 8);
+
+  const float c = p.scale * 1.4426950408889634f;   // softmax in base 2
+  float m_run = -1e30f, l_run = 0.f;
+  f32x16 oacc[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+
+  const int n_tiles = (p.lk + KT - 1) / KT;
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    const int key0 = kt * KT;
+    __syncthreads();   // previous tile fully consumed
+    // ---- stage K (row-major) and V^T: 64 keys x 64 d = 512 16-byte chunks each, 2 per thread
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int idx = tid + it * 256;
+      const int key = idx & 63;        // lane-consecutive keys -> the 8 d-chunks of a key row sit 64 lanes apart
+      const int dch = idx >> 6;        // 0..7
+      const int gk = key0 + key;
+      u32x4 kv4 = {0u, 0u, 0u, 0u}, vv4 = {0u, 0u, 0u, 0u};
+      if (gk < p.lk) {
+        kv4 = *reinterpret_cast<const u32x4*>(kb + (int64_t)gk * p.k_ss + dch * 8);
+        vv4 = *reinterpret_cast<const u32x4*>(vb + (int64_t)gk * p.v_ss + dch * 8);
+      }
+      *reinterpret_cast<u32x4*>(ks + key * K_STRIDE + dch * 16) = kv4;
+      // transpose V: element e of this chunk is d = dch*8 + e
+      uint16_t* vt = reinterpret_cast<uint16_t*>(vts);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        vt[(dch * 8 + 2 * e) * (VT_STRIDE / 2) + key] = (uint16_t)(vv4[e] & 0xffffu);
+        vt[(dch * 8 + 2 * e + 1) * (VT_STRIDE / 2) + key] = (uint16_t)(vv4[e] >> 16);
+      }
+    }
+    __syncthreads();
+
+    // ---- S^T = K Q^T : two 32-key blocks
+    f32x16 st[2];
+#pragma unroll
+    for (int kbk = 0; kbk < 2; ++kbk) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[kbk][r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + (kbk * 32 + l31) * K_STRIDE + kk * 32 + half * 16);
+        st[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st[kbk], 0, 0, 0);
+      }
+    }
+    // lane owns query l31; st[kbk][r] is key  key0 + kbk*32 + (r&3) + 8*(r>>2) + 4*half
+    float mx = -1e30f;
+#pragma unroll
+    for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = key0 + kbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float s = st[kbk][r] * c;
+        s = key < p.lk ? s : -1e30f;
+        st[kbk][r] = s;
+        mx = fmaxf(mx, s);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f(m_run - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = exp2f(st[kbk][r] - m_new);   // masked keys: exp2(-1e30 - m) = 0
+        st[kbk][r] = pv;
+        rs += pv;
+      }
+    rs += __shfl_xor(rs, 32, 64);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+
+    // ---- O^T += V^T P^T.  MFMA k-slot (half, j) of slab s in key block kbk carries key
+    //      kbk*32 + 16 s + 8 (j>>2) + 4 half + (j&3)  -- for BOTH operands.
+#pragma unroll
+    for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)st[kbk][8 * s + j];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const char* vrow = vts + (d * 32 + l31) * VT_STRIDE + (kbk * 32 + 16 * s + 4 * half) * 2;
+          const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow);        // keys +0..3
+          const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + 16);   // keys +8..11
+          u32x4 vv = {lo[0], lo[1], hi[0], hi[1]};
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, oacc[d], 0, 0, 0);
+        }
+      }
+  }
+
+  // ---- normalise and store.  oacc[d][r] = O[q = l31][dim = d*32 + (r&3) + 8*(r>>2) + 4*half]
+  if (q_row < p.lq) {
+    const float inv = 1.0f / l_run;
+    bf16_t* orow = ob + (int64_t)q_row * p.o_ss;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dim = d * 32 + 8 * g + 4 * half;
+        float x0 = oacc[d][4 * g + 0] * inv, x1 = oacc[d][4 * g + 1] * inv;
+        float x2 = oacc[d][4 * g + 2] * inv, x3 = oacc[d][4 * g + 3] * inv;
+        u32x2* dst = reinterpret_cast<u32x2*>(orow + dim);
+        if (p.accumulate) {
+          const u32x2 old = *dst;
+          x0 += __uint_as_float(old[0] << 16);
+          x1 += __uint_as_float(old[0] & 0xffff0000u);
+          x2 += __uint_as_float(old[1] << 16);
+          x3 += __uint_as_float(old[1] & 0xffff0000u);
+        }
+        u32x2 out = {pack2(x0, x1), pack2(x2, x3)};
+        *dst = out;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Temporal attention: one wave per (batch b, pixel p, head h).  Lane = (query i = lane/4,
+// quarter = lane%4 owning 16 of the 64 dims).  K and V of the sequence sit in LDS as fp32.
+__global__ __launch_bounds__(256) void attn_temporal_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                           int nb, int t_len, int hw, int heads, float scale) {
+  __shared__ float kv_s[4][2][16][64 + 4];   // [wave][k|v][frame][dim], +4 floats pad
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t seq = (int64_t)blockIdx.x * 4 + wave;       // over nb*hw*heads
+  const int64_t total = (int64_t)nb * hw * heads;
+  const bool active = seq < total;
+  const int64_t sq = active ? seq : total - 1;
+  const int hd = (int)(sq % heads);
+  const int64_t bp = sq / heads;
+  const int px = (int)(bp % hw);
+  const int bb = (int)(bp / hw);
+  const int C = heads * 64;
+  const int ld = 3 * C;
+  const int64_t row0 = ((int64_t)bb * t_len) * hw + px;     // frame t -> row0 + t*hw
+
+  // stage K, V: 16 frames x 64 dims each = 128 chunks of 8 dims per matrix; lane handles 2+2
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int idx = lane + it * 64;      // 0..127
+    const int fr = idx >> 3, ch = idx & 7;
+    float kf[8], vf[8];
+    if (fr < t_len) {
+      const bf16_t* rp = qkv + (row0 + (int64_t)fr * hw) * ld + hd * 64 + ch * 8;
+      unpack8(*reinterpret_cast<const u32x4*>(rp + C), kf);
+      unpack8(*reinterpret_cast<const u32x4*>(rp + 2 * C), vf);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { kf[e] = 0.f; vf[e] = 0.f; }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      kv_s[wave][0][fr][ch * 8 + e] = kf[e];
+      kv_s[wave][1][fr][ch * 8 + e] = vf[e];
+    }
+  }
+  const int qi = lane >> 2, quarter = lane & 3;
+  float qv[16];
+  {
+    const int fr = qi < t_len ? qi : t_len - 1;
+    const bf16_t* rp = qkv + (row0 + (int64_t)fr * hw) * ld + hd * 64 + quarter * 16;
+    unpack8(*reinterpret_cast<const u32x4*>(rp), qv);
+    unpack8(*reinterpret_cast<const u32x4*>(rp + 8), qv + 8);
+  }
+  __syncthreads();
+
+  float s[16];
+  float mx = -1e30f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    float a = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) a += qv[e] * kv_s[wave][0][j][quarter * 16 + e];
+    a += __shfl_xor(a, 1, 64);
+    a += __shfl_xor(a, 2, 64);
+    a = j < t_len ? a * scale : -1e30f;
+    s[j] = a;
+    mx = fmaxf(mx, a);
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    s[j] = __expf(s[j] - mx);
+    sum += s[j];
+  }
+  const float inv = 1.0f / sum;
+  float o[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) o[e] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const float pj = s[j] * inv;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[e] += pj * kv_s[wave][1][j][quarter * 16 + e];
+  }
+  if (active && qi < t_len) {
+    bf16_t* op = out + (row0 + (int64_t)qi * hw) * C + hd * 64 + quarter * 16;
+    *reinterpret_cast<u32x4*>(op) = pack8(o);
+    *reinterpret_cast<u32x4*>(op + 8) = pack8(o + 8);
+  }
+}
+
+}  // namespace
+
+extern "C" int tc_attn_d64(const TcAttnParams* pp, void* stream) {
+  if (!pp) return TC_EINVAL;
+  const TcAttnParams& p = *pp;
+  if (!p.q || !p.k || !p.v || !p.o) return TC_EINVAL;
+  if (p.batch <= 0 || p.heads <= 0 || p.lq <= 0 || p.lk <= 0 || p.kv_bdiv <= 0) return TC_EINVAL;
+  if (!tc_aligned16(p.q) || !tc_aligned16(p.k) || !tc_aligned16(p.v) || !tc_aligned16(p.o)) return TC_EALIGN;
+  if ((p.q_ss & 7) || (p.k_ss & 7) || (p.v_ss & 7) || (p.o_ss & 7)) return TC_EALIGN;
+  if ((p.q_sb & 7) || (p.k_sb & 7) || (p.v_sb & 7) || (p.o_sb & 7)) return TC_EALIGN;
+  if (p.heads > 65535 || p.batch > 65535) return TC_ESHAPE;
+  dim3 grid((p.lq + 127) / 128, p.heads, p.batch), block(256);
+  hipLaunchKernelGGL(attn_d64_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream), p);
+  TC_LAUNCH_CHECK();
+  return TC_OK;
+}
+
+extern "C" int tc_attn_temporal(const tc_bf16* qkv, tc_bf16* out, int32_t b, int32_t t, int32_t hw,
+                                int32_t heads, float scale, void* stream) {
+  if (!qkv || !out || b <= 0 || t <= 0 || hw <= 0 || heads <= 0) return TC_EINVAL;
+  if (t > 16) return TC_ESHAPE;
+  if (!tc_aligned16(qkv) || !tc_aligned16(out)) return TC_EALIGN;
+  const int64_t total = (int64_t)b * hw * heads;
+  const int64_t nblk = (total + 3) / 4;
+  if (nblk > 0x7fffffffLL) return TC_ESHAPE;
+  hipLaunchKernelGGL(attn_temporal_kernel, dim3((unsigned)nblk), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const bf16_t*>(qkv), reinterpret_cast<bf16_t*>(out), b, t, hw, heads, scale);
+  TC_LAUNCH_CHECK();
+  return TC_OK;
+}

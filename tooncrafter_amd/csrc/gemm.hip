@@ -1,0 +1,331 @@
+// bf16 MFMA GEMM with implicit-GEMM row gather and fused epilogue, gfx950.
+//
+//   C[M, N] = epilogue( gather(A)[M, K] * W[N, K]^T )
+//
+// One kernel serves nn.Linear, Conv2d 1x1 / 3x3 (stride 1|2, optional fused nearest-x2
+// upsample of the source) and Conv3d (3,1,1): activations are channels-last rows, so a
+// convolution tap is just a different source row for the same K-slice of channels.
+//
+// Tiling (wave64): block tile 128x128x64, 4 waves as 2x2, each wave 64x64 = 2x2
+// v_mfma_f32_32x32x16_bf16 sub-tiles (64 fp32 accumulators / lane).  A and B tiles are
+// register-staged (global_load_dwordx4 -> ds_write_b128) into a double-buffered LDS image
+// whose 16-byte chunks are XOR-swizzled by (row>>1)&7, which makes every ds_read_b128 lane
+// group of the MFMA fragment reads conflict-free (MI355X_MICROARCH.md, LDS table).  The
+// loads of tile k+1 are issued before the MFMAs of tile k and written after them, one
+// barrier per K-step.  The epilogue transposes the accumulators through LDS (fp32) so the
+// bias / embedding / activation / residual / GEGLU math and the global stores all run on
+// 16-byte row vectors.  Blocks are numbered so that all N-tiles of one M-tile land on the
+// same XCD (its L2 then serves the re-reads of the A rows).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int STAGE_BYTES = (BM + BN) * BK * 2;  // 32 KiB per stage
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+  return row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+template <int GATHER>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];  // 64 KiB; reused by the epilogue
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int tiles_n = (p.n + BN - 1) / BN;
+  const int tiles_m = (p.m + BM - 1) / BM;
+  const int xcd = blockIdx.x & 7;
+  const int slot = blockIdx.x >> 3;
+  const int tile_m = (slot / tiles_n) * 8 + xcd;
+  const int tile_n = slot % tiles_n;
+  if (tile_m >= tiles_m) return;
+
+  const int64_t bz = blockIdx.z;
+  const bf16_t* __restrict__ a_base = reinterpret_cast<const bf16_t*>(p.a) + bz * p.stride_a;
+  const bf16_t* __restrict__ w_base = reinterpret_cast<const bf16_t*>(p.w) + bz * p.stride_w;
+
+  // ---- loader geometry: thread -> (row lrow + 32 i, 16-byte chunk) of both tiles
+  const int lrow = tid >> 3;
+  const int chunk = tid & 7;
+  const int hw = p.h_out * p.w_out;
+  int a_m[4];
+  bool a_ok[4];
+  int a_f[4], a_y[4], a_x[4];  // frame / y / x (CONV3x3) or t-in-clip in a_y (CONVT3)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = tile_m * BM + lrow + 32 * i;
+    a_m[i] = m;
+    a_ok[i] = m < p.m;
+    a_f[i] = a_y[i] = a_x[i] = 0;
+    if (GATHER == TC_GATHER_CONV3x3) {
+      const int q = m / p.w_out;
+      a_x[i] = m - q * p.w_out;
+      a_f[i] = q / p.h_out;
+      a_y[i] = q - a_f[i] * p.h_out;
+    } else if (GATHER == TC_GATHER_CONVT3) {
+      const int f = m / hw;
+      a_y[i] = f % p.t_len;
+    }
+  }
+  const int hv = p.upsample ? p.h_in * 2 : p.h_in;
+  const int wv = p.upsample ? p.w_in * 2 : p.w_in;
+
+  u32x4 ra[4], rb[4];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  auto load_tile = [&](int kb) {
+    const int k0 = kb * BK;
+    const int kc = k0 + chunk * 8;
+    const bool k_ok = kc < p.k;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = tile_n * BN + lrow + 32 * i;
+      rb[i] = (k_ok && n < p.n)
+                  ? *reinterpret_cast<const u32x4*>(w_base + (int64_t)n * p.ldw + kc)
+                  : zero4;
+    }
+    if (GATHER == TC_GATHER_LINEAR) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        ra[i] = (k_ok && a_ok[i])
+                    ? *reinterpret_cast<const u32x4*>(a_base + (int64_t)a_m[i] * p.lda + kc)
+                    : zero4;
+    } else if (GATHER == TC_GATHER_CONV3x3) {
+      const int tap = k0 / p.cin;
+      const int c0 = k0 - tap * p.cin + chunk * 8;
+      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int iy = a_y[i] * p.stride + dy;
+        int ix = a_x[i] * p.stride + dx;
+        const bool ok = a_ok[i] && iy >= 0 && iy < hv && ix >= 0 && ix < wv;
+        if (p.upsample) { iy >>= 1; ix >>= 1; }
+        const int64_t src = ((int64_t)a_f[i] * p.h_in + iy) * p.w_in + ix;
+        ra[i] = ok ? *reinterpret_cast<const u32x4*>(a_base + src * p.lda + c0) : zero4;
+      }
+    } else {  // CONVT3
+      const int tap = k0 / p.cin;
+      const int c0 = k0 - tap * p.cin + chunk * 8;
+      const int dt = tap - 1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int tt = a_y[i] + dt;
+        const bool ok = a_ok[i] && tt >= 0 && tt < p.t_len;
+        const int64_t src = (int64_t)a_m[i] + (int64_t)dt * hw;
+        ra[i] = ok ? *reinterpret_cast<const u32x4*>(a_base + src * p.lda + c0) : zero4;
+      }
+    }
+  };
+
+  auto store_tile = [&](int stage) {
+    char* sa = smem + stage * STAGE_BYTES;
+    char* sb = sa + BM * BK * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int off = lds_off(lrow + 32 * i, chunk);
+      *reinterpret_cast<u32x4*>(sa + off) = ra[i];
+      *reinterpret_cast<u32x4*>(sb + off) = rb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frow = lane & 31;
+  const int fhalf = lane >> 5;
+
+  auto compute = [&](int stage) {
+    const char* sa = smem + stage * STAGE_BYTES;
+    const char* sb = sa + BM * BK * 2;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int c = kk * 2 + fhalf;
+      bf16x8 af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(wm * 64 + i * 32 + frow, c));
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        bf[j] = *reinterpret_cast<const bf16x8*>(sb + lds_off(wn * 64 + j * 32 + frow, c));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int nk = (p.k + BK - 1) / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kb = 0; kb < nk; ++kb) {
+    const bool more = kb + 1 < nk;
+    if (more) load_tile(kb + 1);
+    compute(kb & 1);
+    if (more) store_tile((kb + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulators -> LDS fp32 [128][128] -> row vectors
+  float* cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+        const int col = wn * 64 + j * 32 + frow;
+        cs[row * BN + col] = acc[i][j][r];
+      }
+  __syncthreads();
+
+  const bool geglu = p.act == TC_ACT_GEGLU;
+  const int groups = geglu ? 8 : 16;          // 8-column groups per output row of this tile
+  const int n_out = geglu ? p.n / 2 : p.n;    // logical output columns
+  const int col_tile0 = geglu ? tile_n * 64 : tile_n * BN;
+  char* c_base = reinterpret_cast<char*>(p.c) + bz * p.stride_c * (p.out_f32 ? 4 : 2);
+  const bool vec_ok = (n_out & 7) == 0;
+
+  for (int v = tid; v < BM * groups; v += 256) {
+    const int row = v / groups;
+    const int g = v - row * groups;
+    const int m = tile_m * BM + row;
+    const int n0 = col_tile0 + g * 8;
+    if (m >= p.m || n0 >= n_out) continue;
+    float x[8];
+    {
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(cs + row * BN + g * 8);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(cs + row * BN + g * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { x[e] = lo[e]; x[4 + e] = hi[e]; }
+    }
+    if (geglu) {
+      float gt[8];
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(cs + row * BN + 64 + g * 8);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(cs + row * BN + 64 + g * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { gt[e] = lo[e]; gt[4 + e] = hi[e]; }
+      const int bn = tile_n * BN + g * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float val = x[e] * p.alpha, gate = gt[e] * p.alpha;
+        if (p.bias) { val += p.bias[bn + e]; gate += p.bias[bn + 64 + e]; }
+        x[e] = val * gelu_erf_f(gate) * p.out_scale;
+      }
+    } else {
+      const float* rbp = p.row_bias ? p.row_bias + (int64_t)(m / p.row_div) * p.ldrb : nullptr;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (n0 + e < n_out) {
+          float val = x[e] * p.alpha;
+          if (p.bias) val += p.bias[n0 + e];
+          if (rbp) val += rbp[n0 + e];
+          if (p.act == TC_ACT_SILU) val = silu_f(val);
+          else if (p.act == TC_ACT_GELU) val = gelu_erf_f(val);
+          x[e] = val * p.out_scale;
+        }
+      }
+    }
+    if (p.residual) {
+      const bf16_t* rp = reinterpret_cast<const bf16_t*>(p.residual) + bz * p.stride_c + (int64_t)m * p.ldr + n0;
+      if (vec_ok) {
+        float rf[8];
+        unpack8(*reinterpret_cast<const u32x4*>(rp), rf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] += rf[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (n0 + e < n_out) x[e] += (float)rp[e];
+      }
+    }
+    if (p.out_f32) {
+      float* op = reinterpret_cast<float*>(c_base) + (int64_t)m * p.ldc + n0;
+      if (vec_ok) {
+        f32x4 lo, hi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lo[e] = x[e]; hi[e] = x[4 + e]; }
+        *reinterpret_cast<f32x4*>(op) = lo;
+        *reinterpret_cast<f32x4*>(op + 4) = hi;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (n0 + e < n_out) op[e] = x[e];
+      }
+    } else {
+      bf16_t* op = reinterpret_cast<bf16_t*>(c_base) + (int64_t)m * p.ldc + n0;
+      if (vec_ok) {
+        *reinterpret_cast<u32x4*>(op) = pack8(x);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (n0 + e < n_out) op[e] = (bf16_t)x[e];
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int tc_gemm_bf16(const TcGemmParams* pp, void* stream) {
+  if (!pp) return TC_EINVAL;
+  const TcGemmParams& p = *pp;
+  if (!p.a || !p.w || !p.c || p.m <= 0 || p.n <= 0 || p.k <= 0) return TC_EINVAL;
+  if (!tc_aligned16(p.a) || !tc_aligned16(p.w) || !tc_aligned16(p.c)) return TC_EALIGN;
+  if (p.residual && !tc_aligned16(p.residual)) return TC_EALIGN;
+  if ((p.k & 7) || (p.lda & 7) || (p.ldw & 7)) return TC_EALIGN;
+  if (p.ldw < p.k) return TC_ESHAPE;
+  const bool geglu = p.act == TC_ACT_GEGLU;
+  const int n_out = geglu ? p.n / 2 : p.n;
+  if ((n_out & 7) == 0) {
+    if (p.out_f32 ? (p.ldc & 3) : (p.ldc & 7)) return TC_EALIGN;
+    if (p.residual && (p.ldr & 7)) return TC_EALIGN;
+  }
+  if (p.ldc < n_out || (p.residual && p.ldr < n_out)) return TC_ESHAPE;
+  if (geglu && ((p.n % 128) != 0 || p.row_bias || p.residual)) return TC_ESHAPE;
+  if (p.row_bias && (p.row_div <= 0 || p.ldrb < p.n)) return TC_EINVAL;
+  if (p.act < TC_ACT_NONE || p.act > TC_ACT_GEGLU) return TC_EINVAL;
+  const int batch = p.batch > 0 ? p.batch : 1;
+  if (p.gather == TC_GATHER_LINEAR) {
+    if (p.lda < p.k) return TC_ESHAPE;
+  } else if (p.gather == TC_GATHER_CONV3x3 || p.gather == TC_GATHER_CONVT3) {
+    const int taps = p.gather == TC_GATHER_CONV3x3 ? 9 : 3;
+    if (p.cin <= 0 || (p.cin % 64) != 0 || p.k != taps * p.cin || p.lda < p.cin) return TC_ESHAPE;
+    if (p.frames <= 0 || p.h_out <= 0 || p.w_out <= 0) return TC_ESHAPE;
+    if ((int64_t)p.frames * p.h_out * p.w_out != p.m) return TC_ESHAPE;
+    if (p.gather == TC_GATHER_CONV3x3) {
+      if (p.h_in <= 0 || p.w_in <= 0 || (p.stride != 1 && p.stride != 2)) return TC_ESHAPE;
+      if (p.upsample && p.stride != 1) return TC_ESHAPE;
+      const int hvv = p.upsample ? 2 * p.h_in : p.h_in, wvv = p.upsample ? 2 * p.w_in : p.w_in;
+      if ((hvv + 2 - 3) / p.stride + 1 != p.h_out || (wvv + 2 - 3) / p.stride + 1 != p.w_out) return TC_ESHAPE;
+    } else {
+      if (p.t_len <= 0 || (p.frames % p.t_len) != 0) return TC_ESHAPE;
+    }
+  } else {
+    return TC_EINVAL;
+  }
+  const int tiles_n = (p.n + BN - 1) / BN;
+  const int tiles_m = (p.m + BM - 1) / BM;
+  const int64_t nblk = (int64_t)tiles_n * 8 * ((tiles_m + 7) / 8);
+  if (nblk > 0x7fffffffLL || batch > 65535) return TC_ESHAPE;
+  dim3 grid((unsigned)nblk, 1, (unsigned)batch), block(256);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  switch (p.gather) {
+    case TC_GATHER_LINEAR: hipLaunchKernelGGL(gemm_kernel<TC_GATHER_LINEAR>, grid, block, 0, s, p); break;
+    case TC_GATHER_CONV3x3: hipLaunchKernelGGL(gemm_kernel<TC_GATHER_CONV3x3>, grid, block, 0, s, p); break;
+    default: hipLaunchKernelGGL(gemm_kernel<TC_GATHER_CONVT3>, grid, block, 0, s, p); break;
+  }
+  TC_LAUNCH_CHECK();
+  return TC_OK;
+}

@@ -1,0 +1,296 @@
+// GroupNorm(32) (+SiLU), LayerNorm and row softmax over channels-last bf16 rows, gfx950.
+// All three are HBM-bound: 16-byte vector loads/stores, fp32 statistics, wave64 shuffles.
+//
+// GroupNorm is two launches:
+//   gn_stats : grid (chunks, samples).  A block walks its chunk of rows with every thread
+//              pinned to one 8-channel vector (so per-channel sums stay in registers), then
+//              folds channels -> groups through LDS and writes one (sum, sumsq) pair per
+//              (sample, chunk, group).  Deterministic: no atomics.
+//   gn_apply : same decomposition; the prologue reduces the per-chunk partials of its sample
+//              to mean / rstd, folds them with gamma/beta into per-channel (scale, shift)
+//              registers, then streams y = silu(x * scale + shift).
+// Algorithmic traffic: read x twice, write y once (the second read mostly hits the 256 MiB
+// Infinity Cache for UNet-sized tensors).
+#include "common.h"
+
+namespace {
+
+constexpr int GN_THREADS = 256;
+constexpr int GN_MAX_SLOTS = 2;       // 8-channel vectors per thread per row pass -> C <= 4096
+constexpr int GN_ROWS_PER_CHUNK = 512;
+
+struct GnGeo {
+  int vpr;         // 8-channel vectors per row (C/8)
+  int slots;       // vector slots per thread (1 or 2)
+  int rows_pp;     // rows processed per pass by one block
+};
+
+__device__ __forceinline__ GnGeo gn_geo(int c) {
+  GnGeo g;
+  g.vpr = c >> 3;
+  g.slots = (g.vpr + GN_THREADS - 1) / GN_THREADS;
+  const int vps = (g.vpr + g.slots - 1) / g.slots;   // vectors per slot-pass
+  g.rows_pp = g.slots > 1 ? 1 : GN_THREADS / vps;
+  if (g.rows_pp < 1) g.rows_pp = 1;
+  return g;
+}
+
+// thread -> (row lane, vector index for slot s); returns -1 when idle
+__device__ __forceinline__ void gn_thread_map(const GnGeo& g, int tid, int& rlane, int (&vec)[GN_MAX_SLOTS]) {
+  if (g.slots > 1) {
+    rlane = 0;
+#pragma unroll
+    for (int s = 0; s < GN_MAX_SLOTS; ++s) {
+      const int v = tid + s * GN_THREADS;
+      vec[s] = (s < g.slots && v < g.vpr) ? v : -1;
+    }
+  } else {
+    rlane = tid / g.vpr;
+    vec[0] = rlane < g.rows_pp ? tid - rlane * g.vpr : -1;
+    if (rlane >= g.rows_pp) rlane = 0;
+    vec[1] = -1;
+  }
+}
+
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ part,
+                                                              int rows, int c, int nchunks) {
+  __shared__ float red[2][4096 + 32];
+  const GnGeo g = gn_geo(c);
+  const int tid = threadIdx.x;
+  int rlane, vec[GN_MAX_SLOTS];
+  gn_thread_map(g, tid, rlane, vec);
+  const int sample = blockIdx.y, chunk = blockIdx.x;
+  const int r0 = chunk * GN_ROWS_PER_CHUNK;
+  const int r1 = min(rows, r0 + GN_ROWS_PER_CHUNK);
+  const bf16_t* xs = x + (int64_t)sample * rows * c;
+
+  float sum[GN_MAX_SLOTS][8], sq[GN_MAX_SLOTS][8];
+#pragma unroll
+  for (int s = 0; s < GN_MAX_SLOTS; ++s)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sum[s][e] = 0.f; sq[s][e] = 0.f; }
+
+  for (int r = r0 + rlane; r < r1; r += g.rows_pp) {
+#pragma unroll
+    for (int s = 0; s < GN_MAX_SLOTS; ++s) {
+      if (vec[s] >= 0) {
+        float f[8];
+        unpack8(*reinterpret_cast<const u32x4*>(xs + (int64_t)r * c + vec[s] * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sum[s][e] += f[e]; sq[s][e] += f[e] * f[e]; }
+      }
+    }
+  }
+  // fold row lanes: per-channel totals in LDS (row lane 0 initialises, others add in turn)
+  for (int pass = 0; pass < g.rows_pp; ++pass) {
+    if (rlane == pass) {
+#pragma unroll
+      for (int s = 0; s < GN_MAX_SLOTS; ++s)
+        if (vec[s] >= 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int ch = vec[s] * 8 + e;
+            if (pass == 0) { red[0][ch] = sum[s][e]; red[1][ch] = sq[s][e]; }
+            else { red[0][ch] += sum[s][e]; red[1][ch] += sq[s][e]; }
+          }
+        }
+    }
+    __syncthreads();
+  }
+  if (tid < 32) {
+    const int cpg = c / 32;
+    float a = 0.f, b = 0.f;
+    for (int i = 0; i < cpg; ++i) { a += red[0][tid * cpg + i]; b += red[1][tid * cpg + i]; }
+    float* o = part + (((int64_t)sample * nchunks + chunk) * 32 + tid) * 2;
+    o[0] = a;
+    o[1] = b;
+  }
+}
+
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ part, int rows, int c, int nchunks,
+                                                              float eps, int silu) {
+  __shared__ float mean_s[32], rstd_s[32];
+  const GnGeo g = gn_geo(c);
+  const int tid = threadIdx.x;
+  int rlane, vec[GN_MAX_SLOTS];
+  gn_thread_map(g, tid, rlane, vec);
+  const int sample = blockIdx.y, chunk = blockIdx.x;
+  if (tid < 32) {
+    double a = 0.0, b = 0.0;
+    const float* pp = part + ((int64_t)sample * nchunks * 32 + tid) * 2;
+    for (int k = 0; k < nchunks; ++k) { a += pp[(int64_t)k * 64]; b += pp[(int64_t)k * 64 + 1]; }
+    const double cnt = (double)rows * (c / 32);
+    const double mean = a / cnt;
+    double var = b / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mean_s[tid] = (float)mean;
+    rstd_s[tid] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const int cpg = c / 32;
+  float sc[GN_MAX_SLOTS][8], sh[GN_MAX_SLOTS][8];
+#pragma unroll
+  for (int s = 0; s < GN_MAX_SLOTS; ++s)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sc[s][e] = 0.f; sh[s][e] = 0.f;
+      if (vec[s] >= 0) {
+        const int ch = vec[s] * 8 + e;
+        const int grp = ch / cpg;
+        const float a = rstd_s[grp] * gamma[ch];
+        sc[s][e] = a;
+        sh[s][e] = beta[ch] - mean_s[grp] * a;
+      }
+    }
+  const int r0 = chunk * GN_ROWS_PER_CHUNK;
+  const int r1 = min(rows, r0 + GN_ROWS_PER_CHUNK);
+  const bf16_t* xs = x + (int64_t)sample * rows * c;
+  bf16_t* ys = y + (int64_t)sample * rows * c;
+  for (int r = r0 + rlane; r < r1; r += g.rows_pp) {
+#pragma unroll
+    for (int s = 0; s < GN_MAX_SLOTS; ++s) {
+      if (vec[s] >= 0) {
+        const int64_t off = (int64_t)r * c + vec[s] * 8;
+        float f[8];
+        unpack8(*reinterpret_cast<const u32x4*>(xs + off), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float v = f[e] * sc[s][e] + sh[s][e];
+          f[e] = silu ? silu_f(v) : v;
+        }
+        *reinterpret_cast<u32x4*>(ys + off) = pack8(f);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, row held in registers (<= 4 vectors of 8 per lane -> C <= 2048),
+// true two-pass variance.
+constexpr int LN_MAXV = 4;
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       int rows, int c, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int vpr = c >> 3;
+  const bf16_t* xr = x + (int64_t)row * c;
+  float f[LN_MAXV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int v = lane + i * 64;
+    if (v < vpr) {
+      unpack8(*reinterpret_cast<const u32x4*>(xr + v * 8), f[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += f[i][e];
+    }
+  }
+  const float mean = wave_sum(s) / (float)c;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int v = lane + i * 64;
+    if (v < vpr) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = f[i][e] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)c + eps);
+  bf16_t* yr = y + (int64_t)row * c;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int v = lane + i * 64;
+    if (v < vpr) {
+      float o[8];
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + v * 8);
+      const f32x4 g1 = *reinterpret_cast<const f32x4*>(gamma + v * 8 + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + v * 8);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(beta + v * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (f[i][e] - mean) * rstd * g0[e] + b0[e];
+        o[4 + e] = (f[i][4 + e] - mean) * rstd * g1[e] + b1[e];
+      }
+      *reinterpret_cast<u32x4*>(yr + v * 8) = pack8(o);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Row softmax fp32 -> bf16, one block per row (rows are L = 2560 wide in the decoder).
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, bf16_t* __restrict__ p,
+                                                          int n, int lds, int ldo) {
+  __shared__ float redm[4], reds[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* sr = s + (int64_t)blockIdx.x * lds;
+  bf16_t* pr = p + (int64_t)blockIdx.x * ldo;
+  float mx = -1e30f;
+  for (int i = tid; i < n; i += 256) mx = fmaxf(mx, sr[i]);
+  mx = wave_max(mx);
+  if (lane == 0) redm[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+  float sum = 0.f;
+  for (int i = tid; i < n; i += 256) sum += __expf(sr[i] - mx);
+  sum = wave_sum(sum);
+  if (lane == 0) reds[wave] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (reds[0] + reds[1] + reds[2] + reds[3]);
+  for (int i = tid; i < n; i += 256) pr[i] = (bf16_t)(__expf(sr[i] - mx) * inv);
+}
+
+}  // namespace
+
+static inline int gn_chunks(int rows) { return (rows + GN_ROWS_PER_CHUNK - 1) / GN_ROWS_PER_CHUNK; }
+
+extern "C" int64_t tc_groupnorm_workspace(int32_t samples, int32_t rows, int32_t c) {
+  (void)c;
+  if (samples <= 0 || rows <= 0) return 0;
+  return (int64_t)samples * gn_chunks(rows) * 32 * 2 * sizeof(float);
+}
+
+extern "C" int tc_groupnorm(const tc_bf16* x, tc_bf16* y, const float* gamma, const float* beta,
+                            int32_t samples, int32_t rows, int32_t c, float eps, int32_t silu,
+                            void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!x || !y || !gamma || !beta || !workspace || samples <= 0 || rows <= 0 || c <= 0) return TC_EINVAL;
+  if ((c % 32) != 0 || c > GN_MAX_SLOTS * GN_THREADS * 8 || c > 4096) return TC_ESHAPE;
+  if ((c % 8) != 0) return TC_ESHAPE;
+  if (!tc_aligned16(x) || !tc_aligned16(y)) return TC_EALIGN;
+  if (workspace_bytes < tc_groupnorm_workspace(samples, rows, c)) return TC_EWORKSPACE;
+  if (samples > 65535) return TC_ESHAPE;
+  const int nch = gn_chunks(rows);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(nch, samples), block(GN_THREADS);
+  hipLaunchKernelGGL(gn_stats_kernel, grid, block, 0, s, reinterpret_cast<const bf16_t*>(x),
+                     reinterpret_cast<float*>(workspace), rows, c, nch);
+  TC_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, s, reinterpret_cast<const bf16_t*>(x),
+                     reinterpret_cast<bf16_t*>(y), gamma, beta, reinterpret_cast<const float*>(workspace), rows, c,
+                     nch, eps, silu);
+  TC_LAUNCH_CHECK();
+  return TC_OK;
+}
+
+extern "C" int tc_layernorm(const tc_bf16* x, tc_bf16* y, const float* gamma, const float* beta,
+                            int32_t rows, int32_t c, float eps, void* stream) {
+  if (!x || !y || !gamma || !beta || rows <= 0 || c <= 0) return TC_EINVAL;
+  if ((c % 8) != 0 || c > LN_MAXV * 64 * 8) return TC_ESHAPE;
+  if (!tc_aligned16(x) || !tc_aligned16(y) || !tc_aligned16(gamma) || !tc_aligned16(beta)) return TC_EALIGN;
+  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const bf16_t*>(x), reinterpret_cast<bf16_t*>(y), gamma, beta, rows, c, eps);
+  TC_LAUNCH_CHECK();
+  return TC_OK;
+}
+
+extern "C" int tc_softmax_rows(const float* s, tc_bf16* p, int32_t rows, int32_t n, int32_t lds, int32_t ldo,
+                               void* stream) {
+  if (!s || !p || rows <= 0 || n <= 0 || lds < n || ldo < n) return TC_EINVAL;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), s,
+                     reinterpret_cast<bf16_t*>(p), n, lds, ldo);
+  TC_LAUNCH_CHECK();
+  return TC_OK;
+}

@@ -1,0 +1,263 @@
+"""Transformer blocks of the UNet on the HIP operators.
+
+Mirrors the interface of reference lvdm/modules/attention.py (class names,
+constructor kwargs, parameter names -> identical state-dict keys):
+CrossAttention (42-209), BasicTransformerBlock (212-246), SpatialTransformer
+(249-310), TemporalTransformer (313-412), GEGLU/FeedForward (415-442).
+
+Differences in HOW (not what) is computed:
+  * q/k/v projections of a self-attention run as one fused [3C, C] GEMM;
+  * every `+ x` residual and bias is folded into the epilogue of the GEMM that
+    produces the branch; GEGLU is the epilogue of the first FF GEMM;
+  * cross-attention K/V depend only on the conditioning, which is constant over
+    the DDIM loop: they are projected once per context (ContextCache) instead of
+    once per UNet call, and the text keys are shared by the T frames of a clip
+    (kv_bdiv) instead of being repeat_interleave'd;
+  * activations stay channels-last, so spatial tokens, temporal tokens and conv
+    pixels are the same rows and no rearrange/permute is ever materialised.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .._lib import ACT_GEGLU
+from .common import Act, PackedModule, f32, pack_geglu, pack_linear
+
+
+class ContextCache:
+    """Cross-attention conditioning prepared once per sampling run.
+
+    `context`: (B, L, Cc) fp32.  With L == 77 + 16*T the tail is per-frame image
+    tokens (reference openaimodel3d.py:556-560); otherwise both parts are shared
+    by all frames of a clip."""
+
+    def __init__(self, context: torch.Tensor, t: int, text_len: int = 77):
+        b, l, cc = context.shape
+        self.b, self.t, self.cc = b, t, cc
+        ctx = context.detach()
+        self.text_len = min(text_len, l)
+        self.text_rows = ctx[:, :self.text_len].reshape(b * self.text_len, cc).to(torch.bfloat16).contiguous()
+        li = l - self.text_len
+        self.img_rows = None
+        self.img_len = 0
+        self.img_per_frame = False
+        if li > 0:
+            if l == 77 + t * 16:
+                self.img_per_frame = True
+                self.img_len = 16
+            else:
+                self.img_len = li
+            self.img_rows = ctx[:, self.text_len:].reshape(b * li, cc).to(torch.bfloat16).contiguous()
+        self.kv = {}          # id(module) -> (kv_text, kv_img)
+        self.key = (context.data_ptr(), context._version, tuple(context.shape), t)
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+
+class FeedForward(PackedModule):
+    def __init__(self, dim, dim_out=None, mult=4, glu=False, dropout=0.):
+        super().__init__()
+        if not glu:
+            raise NotImplementedError("the ToonCrafter config only uses the gated (GEGLU) feed-forward")
+        inner = int(dim * mult)
+        dim_out = dim if dim_out is None else dim_out
+        self.net = nn.Sequential(GEGLU(dim, inner), nn.Dropout(dropout), nn.Linear(inner, dim_out))
+
+    def _pack(self):
+        w1, b1 = pack_geglu(self.net[0].proj.weight, self.net[0].proj.bias)
+        return {"w1": w1, "b1": b1, "w2": pack_linear(self.net[2].weight), "b2": f32(self.net[2].bias)}
+
+    def forward(self, x_norm, residual):
+        pk = self.pk
+        g = ops.gemm(x_norm, pk["w1"], pk["b1"], act=ACT_GEGLU)
+        return ops.gemm(g, pk["w2"], pk["b2"], residual=residual)
+
+
+class CrossAttention(PackedModule):
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0.,
+                 relative_position=False, temporal_length=None, video_length=None,
+                 image_cross_attention=False, image_cross_attention_scale=1.0,
+                 image_cross_attention_scale_learnable=False, text_context_len=77):
+        super().__init__()
+        if dim_head != 64:
+            raise NotImplementedError("HIP attention kernels are specialised for head dim 64")
+        if relative_position:
+            raise NotImplementedError("relative position is unused by inference_512_v1.0.yaml")
+        if image_cross_attention_scale_learnable:
+            raise NotImplementedError("learnable image cross-attention scale is unused by the config")
+        inner = dim_head * heads
+        self.is_self = context_dim is None
+        context_dim = query_dim if context_dim is None else context_dim
+        self.scale = dim_head ** -0.5
+        self.heads, self.dim_head = heads, dim_head
+        self.to_q = nn.Linear(query_dim, inner, bias=False)
+        self.to_k = nn.Linear(context_dim, inner, bias=False)
+        self.to_v = nn.Linear(context_dim, inner, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner, query_dim), nn.Dropout(dropout))
+        self.temporal_length = temporal_length
+        self.image_cross_attention = image_cross_attention
+        self.image_cross_attention_scale = image_cross_attention_scale
+        self.text_context_len = text_context_len
+        if image_cross_attention:
+            self.to_k_ip = nn.Linear(context_dim, inner, bias=False)
+            self.to_v_ip = nn.Linear(context_dim, inner, bias=False)
+
+    def _pack(self):
+        pk = {"wo": pack_linear(self.to_out[0].weight), "bo": f32(self.to_out[0].bias)}
+        if self.is_self:
+            pk["wqkv"] = pack_linear(torch.cat([self.to_q.weight, self.to_k.weight, self.to_v.weight], 0))
+        else:
+            pk["wq"] = pack_linear(self.to_q.weight)
+            pk["wkv"] = pack_linear(torch.cat([self.to_k.weight, self.to_v.weight], 0))
+            if self.image_cross_attention:
+                pk["wkv_ip"] = pack_linear(torch.cat([self.to_k_ip.weight, self.to_v_ip.weight], 0))
+        return pk
+
+    # -- self attention over the H*W tokens of each frame
+    def forward_spatial_self(self, x_norm, residual, act: Act):
+        pk = self.pk
+        c = self.heads * 64
+        qkv = ops.gemm(x_norm, pk["wqkv"])
+        a = ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], batch=act.frames, heads=self.heads,
+                          lq=act.hw, lk=act.hw, scale=self.scale)
+        return ops.gemm(a, pk["wo"], pk["bo"], residual=residual)
+
+    # -- self attention over the T frames at each pixel
+    def forward_temporal_self(self, x_norm, residual, act: Act):
+        pk = self.pk
+        qkv = ops.gemm(x_norm, pk["wqkv"])
+        a = ops.attention_temporal(qkv, b=act.b, t=act.t, hw=act.hw, heads=self.heads, scale=self.scale)
+        return ops.gemm(a, pk["wo"], pk["bo"], residual=residual)
+
+    # -- text + image cross attention: two softmaxes, summed
+    def context_kv(self, ctx: ContextCache):
+        hit = ctx.kv.get(id(self))
+        if hit is None:
+            pk = self.pk
+            kv_text = ops.gemm(ctx.text_rows, pk["wkv"])
+            kv_img = None
+            if self.image_cross_attention and ctx.img_rows is not None:
+                kv_img = ops.gemm(ctx.img_rows, pk["wkv_ip"])
+            hit = ctx.kv[id(self)] = (kv_text, kv_img)
+        return hit
+
+    def forward_cross(self, x_norm, residual, act: Act, ctx: ContextCache):
+        pk = self.pk
+        c = self.heads * 64
+        kv_text, kv_img = self.context_kv(ctx)
+        q = ops.gemm(x_norm, pk["wq"])
+        a = ops.attention(q, kv_text[:, :c], kv_text[:, c:], batch=act.frames, heads=self.heads, lq=act.hw,
+                          lk=ctx.text_len, kv_bdiv=act.t, scale=self.scale)
+        if kv_img is not None:
+            if self.image_cross_attention_scale != 1.0:
+                raise NotImplementedError("image_cross_attention_scale != 1.0")
+            ops.attention(q, kv_img[:, :c], kv_img[:, c:], batch=act.frames, heads=self.heads, lq=act.hw,
+                          lk=ctx.img_len, kv_bdiv=1 if ctx.img_per_frame else act.t, out=a, accumulate=True,
+                          scale=self.scale)
+        return ops.gemm(a, pk["wo"], pk["bo"], residual=residual)
+
+
+class BasicTransformerBlock(PackedModule):
+    def __init__(self, dim, n_heads, d_head, dropout=0., context_dim=None, gated_ff=True, checkpoint=True,
+                 disable_self_attn=False, attention_cls=None, video_length=None, image_cross_attention=False,
+                 image_cross_attention_scale=1.0, image_cross_attention_scale_learnable=False, text_context_len=77):
+        super().__init__()
+        if disable_self_attn:
+            raise NotImplementedError("disable_self_attn is unused by the config")
+        attn_cls = CrossAttention if attention_cls is None else attention_cls
+        self.attn1 = attn_cls(query_dim=dim, heads=n_heads, dim_head=d_head, dropout=dropout, context_dim=None)
+        self.ff = FeedForward(dim, dropout=dropout, glu=gated_ff)
+        self.attn2 = attn_cls(query_dim=dim, context_dim=context_dim, heads=n_heads, dim_head=d_head,
+                              dropout=dropout, video_length=video_length,
+                              image_cross_attention=image_cross_attention,
+                              image_cross_attention_scale=image_cross_attention_scale,
+                              image_cross_attention_scale_learnable=image_cross_attention_scale_learnable,
+                              text_context_len=text_context_len)
+        self.norm1 = nn.LayerNorm(dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.norm3 = nn.LayerNorm(dim)
+
+    def _pack(self):
+        return {f"g{i}": f32(getattr(self, f"norm{i}").weight) for i in (1, 2, 3)} | \
+               {f"b{i}": f32(getattr(self, f"norm{i}").bias) for i in (1, 2, 3)}
+
+    def _ln(self, x, i):
+        return ops.layernorm(x, self.pk[f"g{i}"], self.pk[f"b{i}"], 1e-5)
+
+    def forward_spatial(self, x, act: Act, ctx: ContextCache):
+        x = self.attn1.forward_spatial_self(self._ln(x, 1), x, act)
+        x = self.attn2.forward_cross(self._ln(x, 2), x, act, ctx)
+        return self.ff(self._ln(x, 3), x)
+
+    def forward_temporal(self, x, act: Act):
+        x = self.attn1.forward_temporal_self(self._ln(x, 1), x, act)
+        x = self.attn2.forward_temporal_self(self._ln(x, 2), x, act)   # context=None -> self attention again
+        return self.ff(self._ln(x, 3), x)
+
+
+class SpatialTransformer(PackedModule):
+    def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0., context_dim=None,
+                 use_checkpoint=True, disable_self_attn=False, use_linear=False, video_length=None,
+                 image_cross_attention=False, image_cross_attention_scale_learnable=False):
+        super().__init__()
+        self.in_channels = in_channels
+        inner = n_heads * d_head
+        self.norm = nn.GroupNorm(32, in_channels, eps=1e-6, affine=True)
+        self.use_linear = use_linear
+        self.proj_in = nn.Linear(in_channels, inner) if use_linear else nn.Conv2d(in_channels, inner, 1)
+        self.transformer_blocks = nn.ModuleList([
+            BasicTransformerBlock(inner, n_heads, d_head, dropout=dropout, context_dim=context_dim,
+                                  disable_self_attn=disable_self_attn, checkpoint=use_checkpoint,
+                                  video_length=video_length, image_cross_attention=image_cross_attention,
+                                  image_cross_attention_scale_learnable=image_cross_attention_scale_learnable)
+            for _ in range(depth)])
+        self.proj_out = nn.Linear(inner, in_channels) if use_linear else nn.Conv2d(inner, in_channels, 1)
+
+    def _pack(self):
+        return {"gn_g": f32(self.norm.weight), "gn_b": f32(self.norm.bias),
+                "wi": pack_linear(self.proj_in.weight), "bi": f32(self.proj_in.bias),
+                "wo": pack_linear(self.proj_out.weight), "bo": f32(self.proj_out.bias)}
+
+    def forward(self, act: Act, ctx: ContextCache) -> Act:
+        pk = self.pk
+        h = ops.groupnorm(act.rows, pk["gn_g"], pk["gn_b"], samples=act.frames, rows=act.hw, eps=1e-6)
+        h = ops.gemm(h, pk["wi"], pk["bi"])
+        for blk in self.transformer_blocks:
+            h = blk.forward_spatial(h, act, ctx)
+        return act.like(ops.gemm(h, pk["wo"], pk["bo"], residual=act.rows))
+
+
+class TemporalTransformer(PackedModule):
+    def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0., context_dim=None,
+                 use_checkpoint=True, use_linear=False, only_self_att=True, causal_attention=False,
+                 causal_block_size=1, relative_position=False, temporal_length=None):
+        super().__init__()
+        if not only_self_att or causal_attention or relative_position:
+            raise NotImplementedError("only the non-causal self-attention temporal transformer of the config")
+        if temporal_length is not None and temporal_length > 16:
+            raise NotImplementedError("temporal attention kernel handles up to 16 frames")
+        self.in_channels = in_channels
+        inner = n_heads * d_head
+        self.norm = nn.GroupNorm(32, in_channels, eps=1e-6, affine=True)
+        self.use_linear = use_linear
+        self.proj_in = nn.Linear(in_channels, inner) if use_linear else nn.Conv1d(in_channels, inner, 1)
+        self.transformer_blocks = nn.ModuleList([
+            BasicTransformerBlock(inner, n_heads, d_head, dropout=dropout, context_dim=None,
+                                  checkpoint=use_checkpoint) for _ in range(depth)])
+        self.proj_out = nn.Linear(inner, in_channels) if use_linear else nn.Conv1d(inner, in_channels, 1)
+
+    _pack = SpatialTransformer._pack
+
+    def forward(self, act: Act) -> Act:
+        pk = self.pk
+        h = ops.groupnorm(act.rows, pk["gn_g"], pk["gn_b"], samples=act.b, rows=act.t * act.hw, eps=1e-6)
+        h = ops.gemm(h, pk["wi"], pk["bi"])
+        for blk in self.transformer_blocks:
+            h = blk.forward_temporal(h, act)
+        return act.like(ops.gemm(h, pk["wo"], pk["bo"], residual=act.rows))

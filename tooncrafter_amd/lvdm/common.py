@@ -1,0 +1,126 @@
+"""Shared host-side plumbing of the module mirror: the channels-last activation
+handle and the weight packers that turn reference-layout parameters into the
+bf16 `[N, K]` matrices the HIP GEMM consumes."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+import torch.nn as nn
+
+BF16 = torch.bfloat16
+
+
+def ceil_to(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+@dataclass
+class Act:
+    """A (B, T, H, W, C) activation stored as bf16 rows [B*T*H*W, C]."""
+    rows: torch.Tensor
+    b: int
+    t: int
+    h: int
+    w: int
+
+    @property
+    def frames(self) -> int:
+        return self.b * self.t
+
+    @property
+    def hw(self) -> int:
+        return self.h * self.w
+
+    @property
+    def c(self) -> int:
+        return self.rows.shape[1]
+
+    def like(self, rows, h=None, w=None) -> "Act":
+        return Act(rows, self.b, self.t, self.h if h is None else h, self.w if w is None else w)
+
+
+# --------------------------------------------------------------------------- packers
+def f32(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+def pack_linear(w: torch.Tensor) -> torch.Tensor:
+    """nn.Linear [N, K] / Conv1d-k1 [N, K, 1] / Conv2d-1x1 [N, K, 1, 1] -> bf16 [N, ceil8(K)]."""
+    w = w.detach()
+    w = w.reshape(w.shape[0], -1)
+    n, k = w.shape
+    kp = ceil_to(k, 8)
+    out = torch.zeros((n, kp), dtype=BF16, device=w.device)
+    out[:, :k] = w.to(BF16)
+    return out
+
+
+def pack_conv3x3(w: torch.Tensor, cin_pad: int | None = None) -> torch.Tensor:
+    """Conv2d [Co, Ci, 3, 3] -> bf16 [Co, 9 * Cip], K index = (ky*3 + kx) * Cip + ci."""
+    w = w.detach()
+    co, ci, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    cip = ceil_to(ci, 64) if cin_pad is None else cin_pad
+    out = torch.zeros((co, 9, cip), dtype=BF16, device=w.device)
+    out[:, :, :ci] = w.permute(0, 2, 3, 1).reshape(co, 9, ci).to(BF16)
+    return out.reshape(co, 9 * cip)
+
+
+def pack_convt3(w: torch.Tensor) -> torch.Tensor:
+    """Conv3d [Co, Ci, 3, 1, 1] -> bf16 [Co, 3 * Ci], K index = kt * Ci + ci."""
+    w = w.detach()
+    co, ci = w.shape[:2]
+    assert tuple(w.shape[2:]) == (3, 1, 1) and ci % 64 == 0
+    return w.reshape(co, ci, 3).permute(0, 2, 1).reshape(co, 3 * ci).to(BF16).contiguous()
+
+
+def pack_geglu(w: torch.Tensor, b: torch.Tensor):
+    """GEGLU proj [2F, C] (rows [0,F) values, [F,2F) gates) -> per 128-row block
+    64 value rows followed by their 64 gate rows; bias likewise (fp32)."""
+    w = w.detach()
+    b = b.detach()
+    f2, c = w.shape
+    f = f2 // 2
+    assert f % 64 == 0
+    wv, wg = w[:f].reshape(f // 64, 64, c), w[f:].reshape(f // 64, 64, c)
+    wp = torch.cat([wv, wg], dim=1).reshape(f2, c)
+    bv, bg = b[:f].reshape(f // 64, 64), b[f:].reshape(f // 64, 64)
+    bp = torch.cat([bv, bg], dim=1).reshape(f2)
+    kp = ceil_to(c, 8)
+    out = torch.zeros((f2, kp), dtype=BF16, device=w.device)
+    out[:, :c] = wp.to(BF16)
+    return out, bp.to(torch.float32).contiguous()
+
+
+class PackedModule(nn.Module):
+    """Base for modules that keep reference-layout nn.Parameters (so
+    `load_state_dict(strict=True)` works with the reference's checkpoints) and a
+    lazily built dict of packed device tensors used by forward."""
+
+    def __init__(self):
+        super().__init__()
+        self._pk = None
+
+    def _pack(self) -> dict:
+        raise NotImplementedError
+
+    @property
+    def pk(self) -> dict:
+        if self._pk is None:
+            with torch.no_grad():
+                self._pk = self._pack()
+        return self._pk
+
+    def invalidate(self):
+        for m in self.modules():
+            if isinstance(m, PackedModule):
+                m._pk = None
+
+    def _apply(self, fn, recurse=True):           # .cuda() / .to(): packed copies are stale
+        self._pk = None
+        return super()._apply(fn, recurse)
+
+    def _load_from_state_dict(self, *a, **k):     # new weights: repack on next use
+        self._pk = None
+        return super()._load_from_state_dict(*a, **k)

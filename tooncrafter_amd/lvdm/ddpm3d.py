@@ -1,0 +1,231 @@
+"""Pipeline model: schedule buffers, apply_model, v-parameterisation algebra,
+decode_first_stage.  Interface of reference lvdm/models/ddpm3d.py -- DDPM (41-463:
+register_schedule 124-187, predict_* 240-252), LatentDiffusion (465-1039: scale_arr
+523-528, decode_core 647-679, apply_model 735-750), LatentVisualDiffusion
+(1041-1240), DiffusionWrapper (1243-1310, `hybrid` branch) -- restricted to what the
+inference scripts touch.  Training, losses, logging and EMA are out of scope.
+"""
+from __future__ import annotations
+
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..utils import instantiate_from_config
+from .utils_diffusion import make_beta_schedule, rescale_zero_terminal_snr
+
+
+def _get(node, key, default=None):
+    if isinstance(node, dict):
+        return node.get(key, default)
+    return getattr(node, key, default)
+
+
+class _DeviceModule(nn.Module):
+    """Stands in for pl.LightningModule: an nn.Module with a `.device` property."""
+
+    @property
+    def device(self):
+        for p in self.parameters():
+            return p.device
+        for b in self.buffers():
+            return b.device
+        return torch.device("cpu")
+
+
+class DiffusionWrapper(_DeviceModule):
+    def __init__(self, diff_model_config, conditioning_key):
+        super().__init__()
+        self.diffusion_model = instantiate_from_config(diff_model_config)
+        self.conditioning_key = conditioning_key
+
+    def forward(self, x, t, c_concat: list = None, c_crossattn: list = None, c_adm=None, s=None, mask=None,
+                **kwargs):
+        if self.conditioning_key == 'hybrid':
+            # x (+) c_concat on the channel axis is fused into the UNet's input layout converter
+            cc = c_crossattn[0] if len(c_crossattn) == 1 else torch.cat(c_crossattn, 1)
+            parts = [x] + list(c_concat)
+            if len(parts) > 2:
+                parts = [x, torch.cat(list(c_concat), dim=1)]
+            return self.diffusion_model(None, t, context=cc, x_parts=parts, **kwargs)
+        if self.conditioning_key == 'crossattn':
+            cc = c_crossattn[0] if len(c_crossattn) == 1 else torch.cat(c_crossattn, 1)
+            return self.diffusion_model(x, t, context=cc, **kwargs)
+        raise NotImplementedError(f"conditioning_key '{self.conditioning_key}' (the config uses 'hybrid')")
+
+
+class DDPM(_DeviceModule):
+    def __init__(self, unet_config, timesteps=1000, beta_schedule="linear", loss_type="l2", ckpt_path=None,
+                 ignore_keys=[], load_only_unet=False, monitor=None, use_ema=True, first_stage_key="image",
+                 image_size=256, channels=3, log_every_t=100, clip_denoised=True, linear_start=1e-4,
+                 linear_end=2e-2, cosine_s=8e-3, given_betas=None, original_elbo_weight=0., v_posterior=0.,
+                 l_simple_weight=1., conditioning_key=None, parameterization="eps", scheduler_config=None,
+                 use_positional_encodings=False, learn_logvar=False, logvar_init=0.,
+                 rescale_betas_zero_snr=False):
+        super().__init__()
+        assert parameterization in ["eps", "x0", "v"]
+        if use_ema:
+            raise NotImplementedError("EMA is a training feature (use_ema: False in the inference config)")
+        self.parameterization = parameterization
+        self.cond_stage_model = None
+        self.clip_denoised = clip_denoised
+        self.log_every_t = log_every_t
+        self.first_stage_key = first_stage_key
+        self.channels = channels
+        self.temporal_length = _get(_get(unet_config, "params"), "temporal_length")
+        self.image_size = [image_size, image_size] if isinstance(image_size, int) else image_size
+        self.model = DiffusionWrapper(unet_config, conditioning_key)
+        self.use_ema = use_ema
+        self.rescale_betas_zero_snr = rescale_betas_zero_snr
+        self.v_posterior = v_posterior
+        if monitor is not None:
+            self.monitor = monitor
+        self.register_schedule(given_betas=given_betas, beta_schedule=beta_schedule, timesteps=timesteps,
+                               linear_start=linear_start, linear_end=linear_end, cosine_s=cosine_s)
+
+    def register_schedule(self, given_betas=None, beta_schedule="linear", timesteps=1000, linear_start=1e-4,
+                          linear_end=2e-2, cosine_s=8e-3):
+        betas = given_betas if given_betas is not None else make_beta_schedule(
+            beta_schedule, timesteps, linear_start=linear_start, linear_end=linear_end, cosine_s=cosine_s)
+        if self.rescale_betas_zero_snr:
+            betas = rescale_zero_terminal_snr(betas)
+        alphas = 1. - betas
+        ac = np.cumprod(alphas, axis=0)
+        ac_prev = np.append(1., ac[:-1])
+        self.num_timesteps = int(betas.shape[0])
+        self.linear_start, self.linear_end = linear_start, linear_end
+        t32 = partial(torch.tensor, dtype=torch.float32)
+        reg = self.register_buffer
+        reg('betas', t32(betas))
+        reg('alphas_cumprod', t32(ac))
+        reg('alphas_cumprod_prev', t32(ac_prev))
+        reg('sqrt_alphas_cumprod', t32(np.sqrt(ac)))
+        reg('sqrt_one_minus_alphas_cumprod', t32(np.sqrt(1. - ac)))
+        reg('log_one_minus_alphas_cumprod', t32(np.log(1. - ac)))
+        if self.parameterization != 'v':
+            reg('sqrt_recip_alphas_cumprod', t32(np.sqrt(1. / ac)))
+            reg('sqrt_recipm1_alphas_cumprod', t32(np.sqrt(1. / ac - 1)))
+        else:
+            reg('sqrt_recip_alphas_cumprod', torch.zeros(self.num_timesteps))
+            reg('sqrt_recipm1_alphas_cumprod', torch.zeros(self.num_timesteps))
+        post_var = (1 - self.v_posterior) * betas * (1. - ac_prev) / (1. - ac) + self.v_posterior * betas
+        reg('posterior_variance', t32(post_var))
+        reg('posterior_log_variance_clipped', t32(np.log(np.maximum(post_var, 1e-20))))
+        reg('posterior_mean_coef1', t32(betas * np.sqrt(ac_prev) / (1. - ac)))
+        reg('posterior_mean_coef2', t32((1. - ac_prev) * np.sqrt(alphas) / (1. - ac)))
+
+    # v-parameterisation algebra on torch tensors (API parity; the sampler uses the fused kernel)
+    def _at(self, buf, t, x):
+        return buf.gather(-1, t).reshape(t.shape[0], *((1,) * (x.dim() - 1)))
+
+    def predict_start_from_z_and_v(self, x_t, t, v):
+        return self._at(self.sqrt_alphas_cumprod, t, x_t) * x_t - self._at(self.sqrt_one_minus_alphas_cumprod, t, x_t) * v
+
+    def predict_eps_from_z_and_v(self, x_t, t, v):
+        return self._at(self.sqrt_alphas_cumprod, t, x_t) * v + self._at(self.sqrt_one_minus_alphas_cumprod, t, x_t) * x_t
+
+
+class LatentDiffusion(DDPM):
+    def __init__(self, first_stage_config, cond_stage_config, num_timesteps_cond=None, cond_stage_key="caption",
+                 cond_stage_trainable=False, cond_stage_forward=None, conditioning_key=None, uncond_prob=0.2,
+                 uncond_type="empty_seq", scale_factor=1.0, scale_by_std=False, encoder_type="2d",
+                 only_model=False, noise_strength=0, use_dynamic_rescale=False, base_scale=0.7, turning_step=400,
+                 loop_video=False, fps_condition_type='fs', perframe_ae=False, logdir=None, rand_cond_frame=False,
+                 en_and_decode_n_samples_a_time=None, *args, **kwargs):
+        self.num_timesteps_cond = 1 if num_timesteps_cond is None else num_timesteps_cond
+        self.scale_by_std = scale_by_std
+        kwargs.pop("ckpt_path", None)
+        kwargs.pop("ignore_keys", None)
+        conditioning_key = 'crossattn' if conditioning_key is None else conditioning_key
+        super().__init__(conditioning_key=conditioning_key, *args, **kwargs)
+        self.cond_stage_trainable = cond_stage_trainable
+        self.cond_stage_key = cond_stage_key
+        self.noise_strength = noise_strength
+        self.use_dynamic_rescale = use_dynamic_rescale
+        self.loop_video = loop_video
+        self.fps_condition_type = fps_condition_type
+        self.perframe_ae = perframe_ae
+        self.en_and_decode_n_samples_a_time = en_and_decode_n_samples_a_time
+        if scale_by_std:
+            self.register_buffer('scale_factor', torch.tensor(scale_factor))
+        else:
+            self.scale_factor = scale_factor
+        if use_dynamic_rescale:
+            arr = np.concatenate((np.linspace(1.0, base_scale, turning_step), np.full(self.num_timesteps, base_scale)))
+            self.register_buffer('scale_arr', torch.tensor(arr, dtype=torch.float32))
+        self.first_stage_model = instantiate_from_config(first_stage_config).eval()
+        for p in self.first_stage_model.parameters():
+            p.requires_grad = False
+        self.cond_stage_model = self._instantiate_cond_stage(cond_stage_config)
+        self.first_stage_config, self.cond_stage_config = first_stage_config, cond_stage_config
+        self.clip_denoised = False
+        self.encoder_type = encoder_type
+        self.uncond_prob, self.uncond_type = uncond_prob, uncond_type
+        self.classifier_free_guidance = uncond_prob > 0
+
+    def _instantiate_cond_stage(self, config):
+        model = instantiate_from_config(config)
+        if isinstance(model, nn.Module):
+            model = model.eval()
+            for p in model.parameters():
+                p.requires_grad = False
+        return model
+
+    def get_learned_conditioning(self, c):
+        enc = getattr(self.cond_stage_model, "encode", None)
+        return enc(c) if callable(enc) else self.cond_stage_model(c)
+
+    def get_first_stage_encoding(self, encoder_posterior, noise=None):
+        z = encoder_posterior.sample(noise=noise) if hasattr(encoder_posterior, "sample") else encoder_posterior
+        return self.scale_factor * z
+
+    # ------------------------------------------------------------------ hot path
+    def apply_model(self, x_noisy, t, cond, **kwargs):
+        if not isinstance(cond, dict):
+            cond = {'c_concat' if self.model.conditioning_key == 'concat' else 'c_crossattn':
+                    cond if isinstance(cond, list) else [cond]}
+        out = self.model(x_noisy, t, **cond, **kwargs)
+        return out[0] if isinstance(out, tuple) else out
+
+    def apply_model_cfg(self, x_noisy, t, cond, uncond, **kwargs):
+        """Conditional and unconditional passes as ONE batch-2B UNet call.  Exact: every
+        normalisation and attention in the UNet is per sample."""
+        def cat(key):
+            a, b = cond.get(key), uncond.get(key)
+            if a is None:
+                return None
+            return [torch.cat([ai, bi], dim=0) for ai, bi in zip(a, b)]
+        both = {k: cat(k) for k in cond.keys()}
+        x2 = torch.cat([x_noisy, x_noisy], dim=0)
+        t2 = torch.cat([t, t], dim=0)
+        kw = dict(kwargs)
+        if kw.get("fs") is not None:
+            kw["fs"] = torch.cat([kw["fs"], kw["fs"]], dim=0)
+        out = self.apply_model(x2, t2, both, **kw)
+        b = x_noisy.shape[0]
+        return out[:b].contiguous(), out[b:].contiguous()
+
+    @torch.no_grad()
+    def decode_first_stage(self, z, **kwargs):
+        return self.decode_core(z, **kwargs)
+
+    def decode_core(self, z, **kwargs):
+        """z: (B, C, T, h, w) latent.  The whole clip batch goes through ONE decoder call with
+        timesteps=T (the only geometry in which the dual-reference fusion is well defined for
+        B > 1); for B == 1 this is exactly what the reference's
+        `perframe_ae=True` loop computes."""
+        if z.dim() != 5:
+            raise NotImplementedError("decode_first_stage expects a (B, C, T, h, w) video latent")
+        ref_context = kwargs.get("ref_context")
+        return self.first_stage_model.decoder.decode_clip(z, ref_context, scale=1.0 / float(self.scale_factor))
+
+
+class LatentVisualDiffusion(LatentDiffusion):
+    def __init__(self, img_cond_stage_config, image_proj_stage_config, freeze_embedder=True,
+                 image_proj_model_trainable=True, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.image_proj_model_trainable = image_proj_model_trainable
+        self.embedder = self._instantiate_cond_stage(img_cond_stage_config)
+        self.image_proj_model = self._instantiate_cond_stage(image_proj_stage_config)

@@ -1,0 +1,309 @@
+"""Tensor-level operators of the hot path, bound to the HIP C ABI.
+
+PyTorch is plumbing here: it owns device memory (caching allocator, so outputs
+are stream-ordered and hipGraph-capturable) and the current stream.  Every
+arithmetic operation is a `tc_*` entry point of libtooncrafter_hip.so.
+
+Data convention: activations are bf16 "rows" tensors `[M, C]` (channels-last:
+M = B*T*H*W), possibly column-sliced views of a wider buffer (row stride =
+`stride(0)`, unit column stride).  Weights are packed once by
+`tooncrafter_amd.lvdm.packing`.
+
+The functions below dispatch to the active backend object.  The only backend
+the package ships is `HipOps`; tests may install a CPU emulation of the same
+contract (tests/emu_ops.py) to exercise the host logic without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_SILU, GATHER_CONV3x3, GATHER_CONVT3,
+                   GATHER_LINEAR, TcAttnParams, TcDdimParams, TcGemmParams)
+
+BF16 = torch.bfloat16
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _rows_view(t: torch.Tensor, dtype=BF16):
+    if t.dim() != 2 or t.stride(1) != 1 or t.dtype != dtype:
+        raise ValueError(f"expected a 2-D {dtype} rows tensor with unit column stride, got "
+                         f"{tuple(t.shape)} {t.dtype} strides {t.stride()}")
+    if not t.is_cuda:
+        raise _lib.TooncrafterHipError("HIP operator called with a CPU tensor: the product path is GPU-only")
+    return t
+
+
+class HipOps:
+    """The product backend: ctypes calls into libtooncrafter_hip.so."""
+
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _lib.load()
+        self._ws = {}
+
+    # ------------------------------------------------------------------ workspace
+    def _workspace(self, nbytes: int, device) -> torch.Tensor:
+        # stream-ordered scratch from the caching allocator (capture-safe)
+        return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+    # ------------------------------------------------------------------ GEMM family
+    def gemm(self, a, w, bias=None, *, act=ACT_NONE, residual=None, row_bias=None, row_div=0,
+             alpha=1.0, out_scale=1.0, out=None, out_f32=False, conv=None, batch=1,
+             stride_a=0, stride_w=0, stride_c=0, m=None):
+        """out[M, N'] = act(alpha * gather(a) @ w^T + bias + row_bias[m // row_div]) * out_scale + residual.
+
+        a: rows tensor (for conv modes the SOURCE rows, lda = a.stride(0));
+        w: [N, K] bf16 contiguous; conv: None | dict(kind='3x3'|'t3', frames, t_len, h_in, w_in,
+        h_out, w_out, stride, upsample, cin); batch>1: a/w/out are the first batch item views
+        and stride_* the element strides between items."""
+        a = _rows_view(a)
+        if w.dtype != BF16 or w.dim() != 2 or w.stride(1) != 1:
+            raise ValueError("w must be a [N, K] bf16 tensor with unit column stride")
+        n, k = w.shape
+        n_out = n // 2 if act == ACT_GEGLU else n
+        p = TcGemmParams()
+        if conv is None:
+            mm = a.shape[0] if m is None else m
+            p.gather = GATHER_LINEAR
+            if a.shape[1] < k:
+                raise ValueError(f"A has {a.shape[1]} columns, weight K = {k}")
+        else:
+            kind = conv["kind"]
+            p.gather = GATHER_CONV3x3 if kind == "3x3" else GATHER_CONVT3
+            p.cin = conv["cin"]
+            p.frames = conv["frames"]
+            p.t_len = conv.get("t_len", 1)
+            p.h_out, p.w_out = conv["h_out"], conv["w_out"]
+            p.h_in, p.w_in = conv.get("h_in", conv["h_out"]), conv.get("w_in", conv["w_out"])
+            p.stride = conv.get("stride", 1)
+            p.upsample = 1 if conv.get("upsample", False) else 0
+            mm = p.frames * p.h_out * p.w_out
+            need_rows = p.frames * p.h_in * p.w_in
+            if a.shape[0] < need_rows:
+                raise ValueError(f"conv source has {a.shape[0]} rows, geometry needs {need_rows}")
+        if out is None:
+            out = torch.empty((mm, n_out), dtype=torch.float32 if out_f32 else BF16, device=a.device)
+        else:
+            _rows_view(out, torch.float32 if out_f32 else BF16)
+            if out.shape[0] < mm or out.shape[1] != n_out:
+                raise ValueError(f"out shape {tuple(out.shape)} != ({mm}, {n_out})")
+        p.a, p.w, p.c = a.data_ptr(), w.data_ptr(), out.data_ptr()
+        if bias is not None:
+            if bias.dtype != torch.float32 or bias.numel() != n:
+                raise ValueError("bias must be fp32 [N]")
+            p.bias = bias.data_ptr()
+        if row_bias is not None:
+            if row_bias.dtype != torch.float32 or row_bias.dim() != 2 or row_bias.stride(1) != 1 \
+                    or row_bias.shape[1] != n:
+                raise ValueError("row_bias must be fp32 [R, N] with unit column stride")
+            if row_div <= 0 or row_bias.shape[0] * row_div < mm:
+                raise ValueError("row_bias / row_div do not cover M")
+            p.row_bias = row_bias.data_ptr()
+            p.ldrb = row_bias.stride(0)
+        if residual is not None:
+            _rows_view(residual)
+            if residual.shape[1] != n_out or residual.shape[0] < mm:
+                raise ValueError("residual shape mismatch")
+            p.residual = residual.data_ptr()
+            p.ldr = residual.stride(0)
+        p.m, p.n, p.k = mm, n, k
+        p.lda, p.ldw, p.ldc = a.stride(0), w.stride(0), out.stride(0)
+        p.row_div = row_div
+        p.alpha, p.out_scale = float(alpha), float(out_scale)
+        p.act, p.out_f32 = act, 1 if out_f32 else 0
+        p.batch = batch
+        p.stride_a, p.stride_w, p.stride_c = stride_a, stride_w, stride_c
+        _lib.check(self.lib.tc_gemm_bf16(C.byref(p), _stream()), "tc_gemm_bf16")
+        return out
+
+    # ------------------------------------------------------------------ attention
+    def attention(self, q, k, v, *, batch, heads, lq, lk, kv_bdiv=1, out=None, accumulate=False, scale=None):
+        """q: [batch*lq, heads*64] rows view; k, v: [(batch//kv_bdiv)*lk, heads*64] rows views.
+        out[batch*lq, heads*64] (+)= softmax(q k^T * scale) v per (batch, head)."""
+        q, k, v = _rows_view(q), _rows_view(k), _rows_view(v)
+        hd = heads * 64
+        if q.shape != (batch * lq, hd) or k.shape[1] != hd or v.shape[1] != hd:
+            raise ValueError("attention: head layout mismatch")
+        kvb = (batch + kv_bdiv - 1) // kv_bdiv
+        if k.shape[0] != kvb * lk or v.shape[0] != kvb * lk:
+            raise ValueError("attention: K/V rows != kv_batches * lk")
+        if out is None:
+            if accumulate:
+                raise ValueError("accumulate needs out")
+            out = torch.empty((batch * lq, hd), dtype=BF16, device=q.device)
+        else:
+            _rows_view(out)
+        p = TcAttnParams()
+        p.q, p.k, p.v, p.o = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+        p.batch, p.heads, p.lq, p.lk = batch, heads, lq, lk
+        p.q_ss, p.k_ss, p.v_ss, p.o_ss = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+        p.q_sb, p.k_sb, p.v_sb, p.o_sb = lq * q.stride(0), lk * k.stride(0), lk * v.stride(0), lq * out.stride(0)
+        p.kv_bdiv = kv_bdiv
+        p.accumulate = 1 if accumulate else 0
+        p.scale = float(scale if scale is not None else 64 ** -0.5)
+        _lib.check(self.lib.tc_attn_d64(C.byref(p), _stream()), "tc_attn_d64")
+        return out
+
+    def attention_temporal(self, qkv, *, b, t, hw, heads, scale=None):
+        """qkv: contiguous [b*t*hw, 3*heads*64] with row = (b*T + t)*HW + p -> [b*t*hw, heads*64]."""
+        qkv = _rows_view(qkv)
+        cdim = heads * 64
+        if not qkv.is_contiguous() or qkv.shape != (b * t * hw, 3 * cdim):
+            raise ValueError("attention_temporal: qkv must be contiguous [b*t*hw, 3*C]")
+        out = torch.empty((b * t * hw, cdim), dtype=BF16, device=qkv.device)
+        _lib.check(self.lib.tc_attn_temporal(qkv.data_ptr(), out.data_ptr(), b, t, hw, heads,
+                                             float(scale if scale is not None else 64 ** -0.5), _stream()),
+                   "tc_attn_temporal")
+        return out
+
+    # ------------------------------------------------------------------ norms
+    def groupnorm(self, x, gamma, beta, *, samples, rows, eps, silu=False):
+        """x: contiguous [samples*rows, C]; statistics over (rows, C/32) per (sample, group)."""
+        x = _rows_view(x)
+        c = x.shape[1]
+        if not x.is_contiguous() or x.shape[0] != samples * rows:
+            raise ValueError("groupnorm: x must be contiguous [samples*rows, C]")
+        y = torch.empty_like(x)
+        nbytes = self.lib.tc_groupnorm_workspace(samples, rows, c)
+        ws = self._workspace(nbytes, x.device)
+        _lib.check(self.lib.tc_groupnorm(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), samples,
+                                         rows, c, float(eps), 1 if silu else 0, ws.data_ptr(), nbytes, _stream()),
+                   "tc_groupnorm")
+        return y
+
+    def layernorm(self, x, gamma, beta, eps=1e-5):
+        x = _rows_view(x)
+        if not x.is_contiguous():
+            raise ValueError("layernorm: x must be contiguous")
+        y = torch.empty_like(x)
+        _lib.check(self.lib.tc_layernorm(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                         x.shape[0], x.shape[1], float(eps), _stream()), "tc_layernorm")
+        return y
+
+    def softmax_rows(self, s):
+        """fp32 [rows, n] -> bf16 probabilities [rows, n]."""
+        if s.dtype != torch.float32 or s.dim() != 2 or not s.is_contiguous() or not s.is_cuda:
+            raise ValueError("softmax_rows: contiguous fp32 CUDA [rows, n]")
+        p = torch.empty(s.shape, dtype=BF16, device=s.device)
+        _lib.check(self.lib.tc_softmax_rows(s.data_ptr(), p.data_ptr(), s.shape[0], s.shape[1], s.shape[1],
+                                            s.shape[1], _stream()), "tc_softmax_rows")
+        return p
+
+    # ------------------------------------------------------------------ layout / elementwise
+    def nchw_to_rows(self, x0, x1=None, *, c_pad, scale=1.0):
+        """(B, C0, T, H, W) [+ (B, C1, T, H, W)] fp32 -> bf16 rows [(b t h w), c_pad]."""
+        if x0.dtype != torch.float32 or x0.dim() != 5 or not x0.is_cuda:
+            raise ValueError("nchw_to_rows: fp32 CUDA (B, C, T, H, W)")
+        x0 = x0.contiguous()
+        b, c0, t, h, w = x0.shape
+        c1 = 0
+        if x1 is not None:
+            x1 = x1.contiguous()
+            if x1.dtype != torch.float32 or x1.shape[0] != b or tuple(x1.shape[2:]) != (t, h, w):
+                raise ValueError("nchw_to_rows: second tensor shape mismatch")
+            c1 = x1.shape[1]
+        out = torch.empty((b * t * h * w, c_pad), dtype=BF16, device=x0.device)
+        _lib.check(self.lib.tc_nchw_to_rows(x0.data_ptr(), c0, _ptr(x1), c1, out.data_ptr(), c_pad, b, t, h * w,
+                                            float(scale), _stream()), "tc_nchw_to_rows")
+        return out
+
+    def rows_to_nchw(self, rows, *, c, b, t, h, w):
+        if rows.dim() != 2 or rows.stride(1) != 1 or rows.dtype not in (BF16, torch.float32) or not rows.is_cuda:
+            raise ValueError("rows_to_nchw: 2-D bf16/fp32 CUDA rows")
+        out = torch.empty((b, c, t, h, w), dtype=torch.float32, device=rows.device)
+        _lib.check(self.lib.tc_rows_to_nchw(rows.data_ptr(), 1 if rows.dtype == torch.float32 else 0,
+                                            rows.stride(0), out.data_ptr(), c, b, t, h * w, _stream()),
+                   "tc_rows_to_nchw")
+        return out
+
+    def concat_rows(self, a, b):
+        a, b = _rows_view(a), _rows_view(b)
+        if not a.is_contiguous() or not b.is_contiguous() or a.shape[0] != b.shape[0]:
+            raise ValueError("concat_rows: contiguous inputs with equal rows")
+        out = torch.empty((a.shape[0], a.shape[1] + b.shape[1]), dtype=BF16, device=a.device)
+        _lib.check(self.lib.tc_concat_rows(a.data_ptr(), a.shape[1], b.data_ptr(), b.shape[1], out.data_ptr(),
+                                           a.shape[0], _stream()), "tc_concat_rows")
+        return out
+
+    def timestep_embedding(self, t, dim, ld=None):
+        """t: fp32 [n] -> bf16 [n, ld] = [cos | sin | 0 pad]."""
+        if t.dtype != torch.float32 or t.dim() != 1 or not t.is_cuda:
+            raise ValueError("timestep_embedding: fp32 CUDA [n]")
+        ld = dim if ld is None else ld
+        out = torch.empty((t.shape[0], ld), dtype=BF16, device=t.device)
+        _lib.check(self.lib.tc_timestep_embedding(t.data_ptr(), out.data_ptr(), t.shape[0], dim, ld, _stream()),
+                   "tc_timestep_embedding")
+        return out
+
+    def silu_to_bf16(self, x):
+        if x.dtype != torch.float32 or not x.is_contiguous() or not x.is_cuda:
+            raise ValueError("silu_to_bf16: contiguous fp32 CUDA")
+        y = torch.empty(x.shape, dtype=BF16, device=x.device)
+        _lib.check(self.lib.tc_silu_f32_to_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream()),
+                   "tc_silu_f32_to_bf16")
+        return y
+
+    def time_mix3(self, rows, w, bias, *, b, t, h, w_):
+        """rows: fp32 [b*t*h*w_, ld>=3]; w: fp32 [3,3,3,1,1]; -> (b, 3, t, h, w_) fp32."""
+        if rows.dtype != torch.float32 or rows.dim() != 2 or rows.stride(1) != 1 or not rows.is_cuda:
+            raise ValueError("time_mix3: fp32 CUDA rows")
+        out = torch.empty((b, 3, t, h, w_), dtype=torch.float32, device=rows.device)
+        _lib.check(self.lib.tc_time_mix3(rows.data_ptr(), rows.stride(0), w.data_ptr(), bias.data_ptr(),
+                                         out.data_ptr(), b, t, h * w_, _stream()), "tc_time_mix3")
+        return out
+
+    def ddim_step(self, x, e_cond, e_uncond, noise, *, cfg_scale, guidance_rescale, sqrt_ac, sqrt_1m_ac,
+                  sqrt_a_prev, dir_coef, sigma, x0_rescale, want_x0=True):
+        for tns in (x, e_cond, e_uncond, noise):
+            if tns is not None and (tns.dtype != torch.float32 or not tns.is_contiguous() or not tns.is_cuda):
+                raise ValueError("ddim_step: contiguous fp32 CUDA tensors")
+        b = x.shape[0]
+        n = x.numel() // b
+        x_prev = torch.empty_like(x)
+        x0 = torch.empty_like(x) if want_x0 else None
+        p = TcDdimParams()
+        p.x, p.e_cond, p.e_uncond, p.noise = x.data_ptr(), e_cond.data_ptr(), _ptr(e_uncond), _ptr(noise)
+        p.x_prev, p.pred_x0 = x_prev.data_ptr(), _ptr(x0)
+        p.b, p.n = b, n
+        p.cfg_scale, p.guidance_rescale = float(cfg_scale), float(guidance_rescale)
+        p.sqrt_ac, p.sqrt_1m_ac, p.sqrt_a_prev = float(sqrt_ac), float(sqrt_1m_ac), float(sqrt_a_prev)
+        p.dir_coef, p.sigma, p.x0_rescale = float(dir_coef), float(sigma), float(x0_rescale)
+        nbytes = self.lib.tc_ddim_workspace(b)
+        ws = self._workspace(nbytes, x.device)
+        _lib.check(self.lib.tc_ddim_step(C.byref(p), ws.data_ptr(), nbytes, _stream()), "tc_ddim_step")
+        return x_prev, x0
+
+
+_backend = None
+
+
+def backend():
+    global _backend
+    if _backend is None:
+        _backend = HipOps()       # raises if libtooncrafter_hip.so is missing: no fallback
+    return _backend
+
+
+def set_backend(b):
+    """Test hook: install another implementation of the operator contract."""
+    global _backend
+    prev, _backend = _backend, b
+    return prev
+
+
+def __getattr__(name):   # ops.gemm(...) -> backend().gemm(...)
+    if name.startswith("_"):
+        raise AttributeError(name)
+    return getattr(backend(), name)
