@@ -1,0 +1,286 @@
+#!/usr/bin/env python3
+"""Headline benchmark: interpolated frames/s of the ToonCrafter denoising hot path.
+
+  python bench.py --gpus N --steps K --warmup W
+
+One "step" = one clip through the hot path on every rank: DDIM-50 (CFG 7.5, eta 1,
+uniform_trailing, guidance_rescale 0.7, dynamic rescale) over the 320-channel
+spatio-temporal UNet at 16 x 40 x 64 latents, then the two dual-reference VideoDecoder
+passes (16 frames, then the 14-frame re-decode whose two middle frames are spliced in,
+reference scripts/evaluation/inference.py:244-270) -> (1, 3, 16, 320, 512) per clip.
+Inputs (conditioning, c_concat, reference hidden states, noise source) are resident in
+HBM when the timed region starts.  Clips shard over ranks with no data-path collective;
+rank 0 gathers the decoded clips once at the end of every step (RCCL).  Weights are
+synthetic (tooncrafter_amd/synth.py), generated on the device.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  roofline     : bf16 MFMA GEMM/implicit-conv kernel -- sum(algorithmic FLOP)/sum(duration) over
+                 every launch of one B=2 UNet forward, HIP events on the launch stream;
+  cpu_baseline : the CPU oracle (oracle/unet.py, fp32) timed on ONE full-size UNet forward
+                 on this host, scaled to frames/s by the clip's algorithmic FLOPs.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from tooncrafter_amd import ops, synth  # noqa: E402
+
+UNET_CFG = dict(in_channels=8, out_channels=4, model_channels=320, attention_resolutions=[4, 2, 1],
+                num_res_blocks=2, channel_mult=[1, 2, 4, 4], dropout=0.1, num_head_channels=64,
+                transformer_depth=1, context_dim=1024, use_linear=True, use_checkpoint=False, temporal_conv=True,
+                temporal_attention=True, temporal_selfatt_only=True, use_relative_position=False,
+                use_causal_attention=False, temporal_length=16, addition_attention=True,
+                image_cross_attention=True, default_fs=24, fs_condition=True)
+DD_CFG = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],
+              num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+MODEL_PARAMS = dict(
+    rescale_betas_zero_snr=True, parameterization="v", linear_start=0.00085, linear_end=0.012, num_timesteps_cond=1,
+    timesteps=1000, first_stage_key="video", cond_stage_key="caption", cond_stage_trainable=False,
+    conditioning_key="hybrid", image_size=[40, 64], channels=4, scale_by_std=False, scale_factor=0.18215,
+    use_ema=False, uncond_type="empty_seq", use_dynamic_rescale=True, base_scale=0.7, fps_condition_type="fps",
+    perframe_ae=True, loop_video=True,
+    unet_config=dict(target="lvdm.modules.networks.openaimodel3d.UNetModel", params=UNET_CFG),
+    first_stage_config=dict(target="lvdm.models.autoencoder.AutoencoderKL_Dualref",
+                            params=dict(embed_dim=4, monitor="val/rec_loss", ddconfig=DD_CFG,
+                                        lossconfig=dict(target="torch.nn.Identity"))),
+    cond_stage_config=dict(target="torch.nn.Identity"), img_cond_stage_config=dict(target="torch.nn.Identity"),
+    image_proj_stage_config=dict(target="torch.nn.Identity"))
+
+# algorithmic work per clip, SURVEY.md 8(d) (1 MAC = 2 FLOP, counted on the reference modules)
+TFLOP_UNET_FWD = 12.603
+TFLOP_CLIP = 100 * TFLOP_UNET_FWD + 37.875 + 33.148
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def build_model(device):
+    from tooncrafter_amd.utils import instantiate_from_config
+    with torch.device("meta"):
+        model = instantiate_from_config(dict(target="lvdm.models.ddpm3d.LatentVisualDiffusion", params=MODEL_PARAMS))
+    bufs = {k: v for k, v in instantiate_schedule().items()}
+    model = model.to_empty(device=device).eval()
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            p.copy_(synth.synth_tensor(name, tuple(p.shape), 1234, device))
+        for name, b in model.named_buffers():
+            b.copy_(bufs[name].to(device))
+    model.model.diffusion_model.prepack()
+    model.first_stage_model.decoder.prepack()
+    return model
+
+
+def instantiate_schedule():
+    """The schedule buffers live on `meta` after the meta-device construction; rebuild them on CPU."""
+    from tooncrafter_amd.lvdm.ddpm3d import DDPM
+    import numpy as np
+
+    class M(torch.nn.Module):
+        pass
+    m = M()
+    m.rescale_betas_zero_snr, m.parameterization, m.v_posterior = True, "v", 0.0
+    DDPM.register_schedule(m, beta_schedule="linear", timesteps=1000, linear_start=0.00085, linear_end=0.012)
+    out = dict(m.named_buffers())
+    out["scale_arr"] = torch.tensor(np.concatenate((np.linspace(1.0, 0.7, 400), np.full(1000, 0.7))),
+                                    dtype=torch.float32)
+    return out
+
+
+def make_inputs(device, seed):
+    inp = synth.synth_inputs(1, 16, 40, 64, seed=seed)
+    refs = synth.synth_ref_context(1, 40, 64, ch=128, seed=seed + 100)
+    d = {k: v.to(device) for k, v in inp.items()}
+    d["refs"] = [r.to(device) for r in refs]
+    return d
+
+
+def run_clip(model, sampler, inp, ddim_steps):
+    """scripts/evaluation/inference.py:244-270, from resident conditioning to the decoded clip."""
+    cond = {"c_crossattn": [inp["cond"]], "c_concat": [inp["c_concat"]]}
+    uc = {"c_crossattn": [inp["uncond"]], "c_concat": [inp["c_concat"]]}
+    samples, _ = sampler.sample(S=ddim_steps, conditioning=cond, batch_size=1, shape=(4, 16, 40, 64), verbose=False,
+                                unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=1.0,
+                                cfg_img=None, mask=None, x0=None, fs=inp["fs"], timestep_spacing="uniform_trailing",
+                                guidance_rescale=0.7, x_T=inp["x_T"], unconditional_conditioning_img_nonetext=None)
+    video = model.decode_first_stage(samples, ref_context=inp["refs"])
+    idx = [i for i in range(samples.shape[2]) if i not in (1, samples.shape[2] - 2)]
+    video2 = model.decode_first_stage(samples[:, :, idx].contiguous(), ref_context=inp["refs"])
+    mid = video2.shape[2] // 2
+    video[:, :, 7:9] = video2[:, :, mid - 1:mid + 1]          # splice the two middle frames (inference.py:268-270)
+    return video
+
+
+class GemmProbe:
+    """Brackets every tc_gemm_bf16 launch with HIP events on the launch stream and tallies its
+    algorithmic FLOPs (2*M*N*K with the logical, un-padded K)."""
+
+    def __init__(self, backend):
+        self.b = backend
+        self.orig = backend.gemm
+        self.rec = []
+
+    def __enter__(self):
+        def gemm(a, w, bias=None, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = self.orig(a, w, bias, **kw)
+            e1.record()
+            conv = kw.get("conv")
+            m = out.shape[0] if conv is None and kw.get("m") is None else (kw.get("m") or out.shape[0])
+            self.rec.append((e0, e1, 2.0 * m * w.shape[0] * w.shape[1] * kw.get("batch", 1)))
+            return out
+        self.b.gemm = gemm
+        return self
+
+    def __exit__(self, *a):
+        self.b.gemm = self.orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.rec)
+        fl = sum(f for _, _, f in self.rec)
+        return len(self.rec), ms, fl
+
+
+def measure_roofline(model, inp):
+    un = model.model.diffusion_model
+    x2 = torch.cat([inp["x_T"]] * 2)
+    cc2 = torch.cat([inp["c_concat"]] * 2)
+    ctx2 = torch.cat([inp["cond"], inp["uncond"]])
+    ts = torch.full((2,), 499, device=x2.device, dtype=torch.long)
+    fs2 = torch.cat([inp["fs"]] * 2)
+    with torch.no_grad():
+        un(None, ts, context=ctx2, fs=fs2, x_parts=[x2, cc2])          # warm (context K/V cached)
+        torch.cuda.synchronize()
+        # give the host a head start so that event gaps are not launch-bound
+        big = torch.empty((8192, 8192), device=x2.device, dtype=torch.bfloat16).normal_()
+        for _ in range(6):
+            big @ big
+        with GemmProbe(ops.backend()) as probe:
+            un(None, ts, context=ctx2, fs=fs2, x_parts=[x2, cc2])
+        n, ms, fl = probe.summary()
+    achieved = fl / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "gemm_kernel (tc_gemm_bf16: Linear / implicit-GEMM conv, all gather modes)",
+            "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "launches": n, "avg_launch_us": round(ms * 1e3 / max(n, 1), 2),
+            "algorithmic_tflop_per_unet_fwd_b2": round(fl / 1e12, 3), "gemm_ms_per_unet_fwd_b2": round(ms, 3)}
+
+
+def cpu_baseline(model, inp):
+    """Time the CPU oracle on ONE full-size UNet forward (the unit 94 % of the clip consists of) and
+    compare its output with the HIP path on identical weights and inputs."""
+    from oracle import unet as ounet
+    un = model.model.diffusion_model
+    t0 = time.time()
+    sd = {k: v.detach().float().cpu() for k, v in un.state_dict().items()}
+    x = torch.cat([inp["x_T"], inp["c_concat"]], 1).cpu()
+    ts = torch.tensor([499])
+    with torch.no_grad():
+        t1 = time.time()
+        y = ounet.unet_forward(sd, UNET_CFG, x, ts, inp["cond"].cpu(), inp["fs"].cpu())
+        t_fwd = time.time() - t1
+        yg = un(x.to(inp["x_T"].device), ts.to(inp["x_T"].device), context=inp["cond"], fs=inp["fs"])
+    rel = float((yg.double().cpu() - y.double()).norm() / y.double().norm())
+    clip_s = t_fwd * TFLOP_CLIP / TFLOP_UNET_FWD
+    return {"value": round(16.0 / clip_s, 6), "unit": "frames/s", "cores": torch.get_num_threads(),
+            "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": f"1 full-size UNet forward (B=1, 12.603 TFLOP) of the fp32 CPU oracle: {t_fwd:.1f} s; "
+                      f"scaled by {TFLOP_CLIP:.1f}/{TFLOP_UNET_FWD} TFLOP to one DDIM-50 clip",
+            "unet_fwd_s": round(t_fwd, 2), "parity_rel_l2_hip_vs_oracle_full_size": round(rel, 5),
+            "prep_s": round(t1 - t0, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert ops.backend().name == "hip"
+
+    from tooncrafter_amd.lvdm.ddim import DDIMSampler
+    model = build_model(device)
+    sampler = DDIMSampler(model)
+    inp = make_inputs(device, seed=7 + rank)
+    gather_buf = [torch.empty((1, 3, 16, 320, 512), device=device) for _ in range(world)] if rank == 0 and world > 1 else None
+
+    def step():
+        with torch.no_grad():
+            video = run_clip(model, sampler, inp, args.ddim_steps)
+            if world > 1:
+                dist.gather(video, gather_buf, dst=0)
+        return video
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        video = step()
+    fence()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    finite = bool(torch.isfinite(video).all())
+
+    result = None
+    if rank == 0:
+        frames = 16 * args.steps * world
+        result = {
+            "metric": "interpolated frames/sec, 512x320x16f DDIM-50", "value": round(frames / dt, 4),
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "ToonCrafter_512 320x512x16f ddim_steps=%d CFG 7.5 bf16, 1 clip per GPU "
+                                   "(BASELINE.json configs[1]); sampler + 16f decode + 14f re-decode + splice"
+                                   % args.ddim_steps,
+                       "clips_per_step": world, "parallelism": f"dp{world} (independent clips, one RCCL gather)"},
+            "effective_tflops_per_gpu": round(TFLOP_CLIP * args.steps / dt, 1) if args.ddim_steps == 50 else None,
+            "mfma_fraction_whole_clip": round(TFLOP_CLIP * args.steps / dt / PEAK_BF16_TFLOPS, 4)
+            if args.ddim_steps == 50 else None,
+            "output_finite": finite,
+        }
+    if rank == 0 and not args.no_roofline:
+        result["roofline"] = measure_roofline(model, inp)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(model, inp)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

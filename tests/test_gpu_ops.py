@@ -1,0 +1,278 @@
+"""Per-operator parity on the MI355X: every `tc_*` entry point, called through the C ABI
+(tooncrafter_amd.ops.HipOps -> ctypes -> libtooncrafter_hip.so), against the plain
+PyTorch fp32 statement of the same operator (tests/emu_ops.py) on seeded inputs.
+
+Tolerances: outputs are bf16, so one rounding (2^-9 relative) is the floor; fp32
+accumulation order differs between MFMA tiles and torch, so rel-L2 <= 4e-3 and
+max-abs <= 3 bf16 ulps of the output scale.  fp32-output operators: rel-L2 <= 1e-4
+(inputs are bf16, products exact in fp32, only summation order differs).
+"""
+import math
+
+import pytest
+import torch
+
+from emu_ops import EmuOps
+from tooncrafter_amd._lib import ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_SILU
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from tooncrafter_amd.ops import HipOps
+    return HipOps()
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return EmuOps(round_bf16=True)
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=BF16):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+def check(out, ref, what, rel=4e-3, f32=False):
+    assert out.shape == ref.shape, (what, out.shape, ref.shape)
+    o, r = out.double(), ref.double()
+    assert torch.isfinite(o).all(), f"{what}: non-finite output"
+    err = float((o - r).norm() / (r.norm() + 1e-30))
+    mx = float((o - r).abs().max())
+    scale = float(r.abs().max()) + 1e-30
+    bound = (1e-4 if f32 else rel)
+    ulps = mx / (scale * 2 ** -8)
+    msg = f"{what}: rel-L2 {err:.3e} max-abs {mx:.3e} (scale {scale:.3e}, {ulps:.2f} bf16-ulp of scale)"
+    print(msg)
+    assert err <= bound, msg
+    if not f32:
+        assert ulps <= 4.0, msg
+
+
+# --------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 320, 320), (1, 1280, 320), (2, 2400, 1280),
+                                    (77, 640, 1024), (300, 4, 576), (1000, 96, 96), (4096, 1280, 2560)])
+def test_gemm_linear(hip, emu, m, n, k):
+    a, w = rnd(m, k, seed=1), rnd(n, k, seed=2, scale=k ** -0.5)
+    bias = rnd(n, seed=3, dtype=torch.float32)
+    check(hip.gemm(a, w, bias), emu.gemm(a, w, bias), f"gemm {m}x{n}x{k}")
+
+
+def test_gemm_transpose_detecting(hip, emu):
+    """A = I-like with asymmetric B: a swapped C-write (row<->col) cannot pass."""
+    n = 256
+    a = torch.eye(n, device=DEV, dtype=BF16)
+    w = (torch.arange(n, device=DEV)[:, None] * 3 + torch.arange(n, device=DEV)[None, :] % 7).float()
+    w = (w / w.max()).to(BF16)
+    out = hip.gemm(a, w)
+    assert torch.equal(out, w.t().contiguous()), "C-write layout (row/col) is wrong"
+
+
+def test_gemm_epilogues(hip, emu):
+    m, n, k = 640, 320, 640
+    a, w = rnd(m, k, seed=4), rnd(n, k, seed=5, scale=k ** -0.5)
+    bias = rnd(n, seed=6, dtype=torch.float32)
+    res = rnd(m, n, seed=7)
+    rb = rnd(5, n + 64, seed=8, dtype=torch.float32)[:, 32:32 + n]          # strided row_bias view
+    for act in (ACT_NONE, ACT_SILU, ACT_GELU):
+        o = hip.gemm(a, w, bias, act=act, residual=res, row_bias=rb, row_div=128, alpha=0.5, out_scale=0.75)
+        r = emu.gemm(a, w, bias, act=act, residual=res, row_bias=rb, row_div=128, alpha=0.5, out_scale=0.75)
+        check(o, r, f"gemm epilogue act={act}")
+    o = hip.gemm(a, w, bias, out_f32=True)
+    check(o, emu.gemm(a, w, bias, out_f32=True), "gemm fp32 out", f32=True)
+    # strided A (column slice of a fused buffer) and strided output (write into a wider buffer)
+    big = rnd(m, 3 * k, seed=9)
+    outbuf = torch.zeros((m, 2 * n), dtype=BF16, device=DEV)
+    hip.gemm(big[:, k:2 * k], w, bias, out=outbuf[:, n:])
+    check(outbuf[:, n:], emu.gemm(big[:, k:2 * k], w, bias), "gemm strided A / strided C")
+    assert float(outbuf[:, :n].abs().max()) == 0.0, "strided output wrote outside its columns"
+    # in-place accumulate: residual and out alias (Combiner)
+    x = rnd(m, n, seed=10)
+    ref = emu.gemm(a, w, bias, residual=x)
+    hip.gemm(a, w, bias, residual=x, out=x)
+    check(x, ref, "gemm in-place residual")
+
+
+def test_gemm_geglu(hip, emu):
+    from tooncrafter_amd.lvdm.common import pack_geglu
+    m, c = 512, 320
+    x = rnd(m, c, seed=11)
+    w = rnd(8 * c, c, seed=12, scale=c ** -0.5, dtype=torch.float32)
+    b = rnd(8 * c, seed=13, dtype=torch.float32)
+    wp, bp = pack_geglu(w, b)
+    out = hip.gemm(x, wp, bp, act=ACT_GEGLU)
+    full = x.float() @ w.to(BF16).float().t() + b
+    v, gate = full.chunk(2, dim=-1)
+    ref = (v * torch.nn.functional.gelu(gate)).to(BF16)
+    check(out, ref, "gemm GEGLU (packed weights) vs unpacked definition")
+
+
+@pytest.mark.parametrize("frames,h,w,cin,cout,stride,ups", [
+    (2, 8, 8, 64, 64, 1, False), (3, 5, 8, 128, 320, 1, False), (2, 10, 16, 64, 128, 2, False),
+    (2, 7, 9, 64, 64, 2, False), (2, 5, 8, 128, 128, 1, True), (1, 40, 64, 320, 320, 1, False),
+    (2, 6, 6, 64, 3, 1, False)])
+def test_gemm_conv3x3(hip, emu, frames, h, w, cin, cout, stride, ups):
+    x = rnd(frames * h * w, cin, seed=14)
+    wt = rnd(cout, 9 * cin, seed=15, scale=(9 * cin) ** -0.5)
+    bias = rnd(cout, seed=16, dtype=torch.float32)
+    ho = h * 2 if ups else (h - 1) // stride + 1
+    wo = w * 2 if ups else (w - 1) // stride + 1
+    geom = dict(kind="3x3", frames=frames, cin=cin, h_in=h, w_in=w, h_out=ho, w_out=wo, stride=stride, upsample=ups)
+    f32 = cout == 3
+    o = hip.gemm(x, wt, bias, conv=geom, out_f32=f32)
+    r = emu.gemm(x, wt, bias, conv=geom, out_f32=f32)
+    check(o, r, f"conv3x3 f{frames} {h}x{w} {cin}->{cout} s{stride} ups{ups}", f32=f32)
+
+
+def test_gemm_conv3x3_matches_torch_conv2d(hip):
+    """The packed-weight convention itself: against F.conv2d on NCHW, not against the emulation."""
+    from tooncrafter_amd.lvdm.common import pack_conv3x3
+    frames, h, w, cin, cout = 2, 9, 7, 64, 128
+    x = rnd(frames, cin, h, w, seed=17)
+    wt = rnd(cout, cin, 3, 3, seed=18, scale=(9 * cin) ** -0.5, dtype=torch.float32)
+    bias = rnd(cout, seed=19, dtype=torch.float32)
+    ref = torch.nn.functional.conv2d(x.float(), wt.to(BF16).float(), bias, padding=1)
+    rows = x.permute(0, 2, 3, 1).reshape(frames * h * w, cin).contiguous()
+    geom = dict(kind="3x3", frames=frames, cin=cin, h_in=h, w_in=w, h_out=h, w_out=w, stride=1, upsample=False)
+    out = hip.gemm(rows, pack_conv3x3(wt), bias, conv=geom)
+    check(out, ref.permute(0, 2, 3, 1).reshape(frames * h * w, cout).to(BF16), "conv3x3 vs F.conv2d")
+
+
+@pytest.mark.parametrize("b,t,hw,c", [(1, 16, 40, 64), (2, 4, 64, 128), (1, 3, 24, 320), (2, 1, 16, 64)])
+def test_gemm_convt3(hip, emu, b, t, hw, c):
+    x = rnd(b * t * hw, c, seed=20)
+    wt = rnd(c, 3 * c, seed=21, scale=(3 * c) ** -0.5)
+    bias = rnd(c, seed=22, dtype=torch.float32)
+    res = rnd(b * t * hw, c, seed=23)
+    geom = dict(kind="t3", frames=b * t, t_len=t, cin=c, h_out=1, w_out=hw)
+    check(hip.gemm(x, wt, bias, conv=geom, residual=res, out_scale=0.3),
+          emu.gemm(x, wt, bias, conv=geom, residual=res, out_scale=0.3), f"convt3 b{b} t{t} hw{hw} c{c}")
+
+
+def test_gemm_batched(hip, emu):
+    f, l, c = 3, 200, 128
+    q, k = rnd(f * l, c, seed=24), rnd(f * l, c, seed=25)
+    s_h = torch.empty((f * l, l), dtype=torch.float32, device=DEV)
+    s_e = torch.empty_like(s_h)
+    kw = dict(alpha=c ** -0.5, out_f32=True, batch=f, stride_a=l * c, stride_w=l * c, stride_c=l * l)
+    hip.gemm(q[:l], k[:l], out=s_h[:l], **kw)
+    emu.gemm(q[:l], k[:l], out=s_e[:l], **kw)
+    check(s_h, s_e, "batched gemm (scores)", f32=True)
+
+
+# --------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("batch,heads,lq,lk,kv_bdiv", [
+    (2, 2, 128, 128, 1), (3, 5, 160, 160, 1), (2, 1, 40, 40, 1), (4, 2, 64, 77, 2), (4, 2, 100, 16, 1),
+    (2, 5, 2560, 2560, 1), (4, 8, 240, 480, 4), (1, 1, 1, 1, 1), (2, 3, 130, 65, 1)])
+def test_attention_d64(hip, emu, batch, heads, lq, lk, kv_bdiv):
+    c = heads * 64
+    kvb = (batch + kv_bdiv - 1) // kv_bdiv
+    q = rnd(batch * lq, c, seed=30)
+    kv = rnd(kvb * lk, 2 * c, seed=31)
+    o = hip.attention(q, kv[:, :c], kv[:, c:], batch=batch, heads=heads, lq=lq, lk=lk, kv_bdiv=kv_bdiv)
+    r = emu.attention(q, kv[:, :c], kv[:, c:], batch=batch, heads=heads, lq=lq, lk=lk, kv_bdiv=kv_bdiv)
+    check(o, r, f"attention b{batch} h{heads} lq{lq} lk{lk} div{kv_bdiv}", rel=8e-3)
+
+
+def test_attention_accumulate_and_spike(hip, emu):
+    batch, heads, lq, lk = 2, 2, 96, 200
+    c = heads * 64
+    q, k, v = rnd(batch * lq, c, seed=32), rnd(batch * lk, c, seed=33), rnd(batch * lk, c, seed=34)
+    # force the online-softmax rescale: one key far above the rest, late in the sequence
+    k[150] = q[7] * 4.0
+    base = rnd(batch * lq, c, seed=35)
+    o = base.clone()
+    hip.attention(q, k, v, batch=batch, heads=heads, lq=lq, lk=lk, out=o, accumulate=True)
+    r = base.clone()
+    emu.attention(q, k, v, batch=batch, heads=heads, lq=lq, lk=lk, out=r, accumulate=True)
+    check(o, r, "attention accumulate + max spike", rel=8e-3)
+
+
+@pytest.mark.parametrize("b,t,hw,heads", [(1, 16, 40, 5), (2, 4, 64, 1), (1, 16, 7, 8), (2, 3, 5, 2), (1, 1, 9, 1)])
+def test_attention_temporal(hip, emu, b, t, hw, heads):
+    qkv = rnd(b * t * hw, 3 * heads * 64, seed=36)
+    check(hip.attention_temporal(qkv, b=b, t=t, hw=hw, heads=heads),
+          emu.attention_temporal(qkv, b=b, t=t, hw=hw, heads=heads), f"temporal attn b{b} t{t} hw{hw} h{heads}",
+          rel=8e-3)
+
+
+# --------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("samples,rows,c,silu,eps", [
+    (32, 40, 1280, True, 1e-5), (4, 2560, 320, True, 1e-5), (2, 16 * 640, 640, False, 1e-6),
+    (3, 100, 64, True, 1e-6), (2, 50, 2560, True, 1e-5), (1, 16 * 2560, 320, True, 1e-5),
+    (2, 1000, 128, True, 1e-6), (5, 7, 960, False, 1e-5), (2, 30, 1920, True, 1e-5)])
+def test_groupnorm(hip, emu, samples, rows, c, silu, eps):
+    x = rnd(samples * rows, c, seed=40) * 2.0 + 0.5
+    g, b = rnd(c, seed=41, dtype=torch.float32) * 0.1 + 1.0, rnd(c, seed=42, dtype=torch.float32) * 0.1
+    check(hip.groupnorm(x, g, b, samples=samples, rows=rows, eps=eps, silu=silu),
+          emu.groupnorm(x, g, b, samples=samples, rows=rows, eps=eps, silu=silu),
+          f"groupnorm s{samples} r{rows} c{c} silu{silu}")
+
+
+@pytest.mark.parametrize("rows,c", [(1000, 320), (77, 640), (5, 1280), (333, 512), (64, 64)])
+def test_layernorm(hip, emu, rows, c):
+    x = rnd(rows, c, seed=43) * 3.0 - 1.0
+    g, b = rnd(c, seed=44, dtype=torch.float32) * 0.1 + 1.0, rnd(c, seed=45, dtype=torch.float32) * 0.1
+    check(hip.layernorm(x, g, b), emu.layernorm(x, g, b), f"layernorm {rows}x{c}")
+
+
+def test_softmax_rows(hip, emu):
+    s = rnd(300, 2560, seed=46, dtype=torch.float32) * 3.0
+    check(hip.softmax_rows(s), emu.softmax_rows(s), "softmax_rows")
+
+
+# --------------------------------------------------------------------------- layout / elementwise
+def test_layout_roundtrip(hip, emu):
+    x0 = rnd(2, 4, 3, 5, 8, seed=47, dtype=torch.float32)
+    x1 = rnd(2, 4, 3, 5, 8, seed=48, dtype=torch.float32)
+    rows = hip.nchw_to_rows(x0, x1, c_pad=64, scale=0.5)
+    assert torch.equal(rows, emu.nchw_to_rows(x0, x1, c_pad=64, scale=0.5))
+    back = hip.rows_to_nchw(rows, c=8, b=2, t=3, h=5, w=8)
+    assert torch.equal(back, emu.rows_to_nchw(rows, c=8, b=2, t=3, h=5, w=8))
+    rf = rnd(2 * 3 * 40, 4, seed=49, dtype=torch.float32)
+    assert torch.equal(hip.rows_to_nchw(rf, c=4, b=2, t=3, h=5, w=8), emu.rows_to_nchw(rf, c=4, b=2, t=3, h=5, w=8))
+    a, b = rnd(1000, 320, seed=50), rnd(1000, 640, seed=51)
+    assert torch.equal(hip.concat_rows(a, b), torch.cat([a, b], 1))
+
+
+def test_embedding_helpers(hip, emu):
+    t = torch.tensor([999.0, 19.0, 0.0, 10.0], device=DEV)
+    check(hip.timestep_embedding(t, 320, 320), emu.timestep_embedding(t, 320, 320), "timestep_embedding")
+    x = rnd(4, 1280, seed=52, dtype=torch.float32)
+    check(hip.silu_to_bf16(x), emu.silu_to_bf16(x), "silu_to_bf16")
+
+
+def test_time_mix3(hip, emu):
+    b, t, h, w = 2, 5, 6, 8
+    rows = rnd(b * t * h * w, 3, seed=53, dtype=torch.float32)
+    wt, bias = rnd(27, seed=54, dtype=torch.float32), rnd(3, seed=55, dtype=torch.float32)
+    check(hip.time_mix3(rows, wt, bias, b=b, t=t, h=h, w_=w), emu.time_mix3(rows, wt, bias, b=b, t=t, h=h, w_=w),
+          "time_mix3", f32=True)
+
+
+@pytest.mark.parametrize("cfg,resc,noise", [(7.5, 0.7, True), (7.5, 0.0, False), (1.0, 0.0, True)])
+def test_ddim_step(hip, emu, cfg, resc, noise):
+    shape = (2, 4, 16, 40, 64)
+    x, ec, eu = (rnd(*shape, seed=s, dtype=torch.float32) for s in (56, 57, 58))
+    nz = rnd(*shape, seed=59, dtype=torch.float32) if noise else None
+    sc = dict(sqrt_ac=0.6, sqrt_1m_ac=0.8, sqrt_a_prev=0.7, dir_coef=0.5, sigma=0.3 if noise else 0.0, x0_rescale=0.98)
+    eu_arg = eu if cfg != 1.0 else None
+    xp, x0 = hip.ddim_step(x, ec, eu_arg, nz, cfg_scale=cfg, guidance_rescale=resc, **sc)
+    rp, r0 = emu.ddim_step(x, ec, eu_arg, nz, cfg_scale=cfg, guidance_rescale=resc, **sc)
+    check(xp, rp, f"ddim x_prev cfg{cfg} resc{resc}", f32=True)
+    check(x0, r0, f"ddim pred_x0 cfg{cfg} resc{resc}", f32=True)
+
+
+# --------------------------------------------------------------------------- error behaviour
+def test_bad_arguments_raise(hip):
+    from tooncrafter_amd._lib import TooncrafterHipError
+    a, w = rnd(64, 64), rnd(64, 64)
+    with pytest.raises((TooncrafterHipError, ValueError)):
+        hip.gemm(a.cpu(), w)                               # CPU tensor: product path is GPU-only
+    with pytest.raises((TooncrafterHipError, ValueError)):
+        hip.gemm(a[:, :60], w[:, :60].contiguous())        # K not a multiple of 8
+    with pytest.raises((TooncrafterHipError, ValueError)):
+        hip.groupnorm(rnd(10, 48), torch.ones(48, device=DEV), torch.zeros(48, device=DEV), samples=1, rows=10, eps=1e-5)
