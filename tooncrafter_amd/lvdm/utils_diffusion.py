@@ -16,7 +16,7 @@ def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2,
     if schedule != "linear":
         raise NotImplementedError(f"beta schedule '{schedule}' (the ToonCrafter config uses 'linear')")
     lo, hi = linear_start ** 0.5, linear_end ** 0.5
-    return (torch.linspace(lo, hi, n_timestep, dtype=torch.float64) ** 2).numpy()
+    return (torch.linspace(lo, hi, n_timestep, dtype=torch.float64, device="cpu") ** 2).numpy()
 
 
 def rescale_zero_terminal_snr(betas):
