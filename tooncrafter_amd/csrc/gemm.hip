@@ -12,10 +12,13 @@
 // whose 16-byte chunks are XOR-swizzled by (row>>1)&7, which makes every ds_read_b128 lane
 // group of the MFMA fragment reads conflict-free (MI355X_MICROARCH.md, LDS table).  The
 // loads of tile k+1 are issued before the MFMAs of tile k and written after them, one
-// barrier per K-step.  The epilogue transposes the accumulators through LDS (fp32) so the
-// bias / embedding / activation / residual / GEGLU math and the global stores all run on
-// 16-byte row vectors.  Blocks are numbered so that all N-tiles of one M-tile land on the
-// same XCD (its L2 then serves the re-reads of the A rows).
+// barrier per K-step.  All tile loads are branch-free: out-of-range rows / taps / K-tails
+// read a clamped in-bounds address and are zeroed by a select, so the eight loads of a
+// K-step always issue back to back (a per-load branch makes hipcc serialise them).
+// The epilogue transposes the accumulators through LDS (fp32) so the bias / embedding /
+// activation / residual / GEGLU math and the global stores run on 16-byte row vectors, with
+// a fully unrolled, unconditional fast path for whole vectors.  Blocks are numbered so that
+// all N-tiles of one M-tile land on the same XCD (its L2 then serves the A re-reads).
 #include "common.h"
 
 namespace {
@@ -25,6 +28,127 @@ constexpr int STAGE_BYTES = (BM + BN) * BK * 2;  // 32 KiB per stage
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+__device__ __forceinline__ u32x4 mask4(const u32x4& v, bool keep) {
+  const uint32_t m = keep ? 0xffffffffu : 0u;
+  return u32x4{v[0] & m, v[1] & m, v[2] & m, v[3] & m};
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == TC_ACT_SILU) return silu_f(v);
+  if (act == TC_ACT_GELU) return gelu_erf_f(v);
+  return v;
+}
+
+// ---- epilogue over the fp32 tile staged in LDS ----------------------------------------
+// Fast path: every 8-column vector of the tile is fully inside N and 16-byte addressable.
+template <bool GEGLU>
+__device__ __forceinline__ void epilogue_fast(const TcGemmParams& p, const float* cs, int tid, int tile_m, int tile_n,
+                                              int64_t bz) {
+  constexpr int GROUPS = GEGLU ? 8 : 16;       // 8-column groups per output row of this tile
+  constexpr int ITERS = BM * GROUPS / 256;     // 4 or 8
+  constexpr int ROWS_PER_IT = 256 / GROUPS;    // 32 or 16
+  const int g = tid % GROUPS;
+  const int row0 = tid / GROUPS;
+  const int n_out = GEGLU ? p.n / 2 : p.n;
+  const int n0 = (GEGLU ? tile_n * 64 : tile_n * BN) + g * 8;
+  if (n0 >= n_out) return;
+  float bv[8], bg[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { bv[e] = 0.f; bg[e] = 0.f; }
+  if (p.bias) {
+    const float* bp = p.bias + (GEGLU ? tile_n * BN + g * 8 : n0);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
+    if (GEGLU) {
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(bp + 64), g1 = *reinterpret_cast<const f32x4*>(bp + 68);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bg[e] = g0[e]; bg[4 + e] = g1[e]; }
+    }
+  }
+  const bf16_t* res_base = p.residual ? reinterpret_cast<const bf16_t*>(p.residual) + bz * p.stride_c : nullptr;
+  char* c_base = reinterpret_cast<char*>(p.c) + bz * p.stride_c * (p.out_f32 ? 4 : 2);
+  // issue all residual / row-bias loads first
+  u32x4 rres[ITERS];
+  f32x4 rb0[ITERS], rb1[ITERS];
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int m = tile_m * BM + row0 + it * ROWS_PER_IT;
+    const int mc = m < p.m ? m : p.m - 1;
+    rres[it] = u32x4{0u, 0u, 0u, 0u};
+    rb0[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+    rb1[it] = rb0[it];
+    if (res_base) rres[it] = *reinterpret_cast<const u32x4*>(res_base + (int64_t)mc * p.ldr + n0);
+    if (!GEGLU && p.row_bias) {
+      const float* rp = p.row_bias + (int64_t)(mc / p.row_div) * p.ldrb + n0;
+      rb0[it] = *reinterpret_cast<const f32x4*>(rp);
+      rb1[it] = *reinterpret_cast<const f32x4*>(rp + 4);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int row = row0 + it * ROWS_PER_IT;
+    const int m = tile_m * BM + row;
+    float x[8];
+    {
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(cs + row * BN + g * 8);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(cs + row * BN + g * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { x[e] = lo[e]; x[4 + e] = hi[e]; }
+    }
+    if (GEGLU) {
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(cs + row * BN + 64 + g * 8);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(cs + row * BN + 64 + g * 8 + 4);
+      float gt[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { gt[e] = lo[e]; gt[4 + e] = hi[e]; }
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        x[e] = (x[e] * p.alpha + bv[e]) * gelu_erf_f(gt[e] * p.alpha + bg[e]) * p.out_scale;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float rbv = e < 4 ? rb0[it][e] : rb1[it][e - 4];
+        x[e] = apply_act(x[e] * p.alpha + bv[e] + rbv, p.act) * p.out_scale;
+      }
+    }
+    if (res_base) {
+      float rf[8];
+      unpack8(rres[it], rf);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] += rf[e];
+    }
+    if (m < p.m) {
+      if (p.out_f32) {
+        float* op = reinterpret_cast<float*>(c_base) + (int64_t)m * p.ldc + n0;
+        *reinterpret_cast<f32x4*>(op) = f32x4{x[0], x[1], x[2], x[3]};
+        *reinterpret_cast<f32x4*>(op + 4) = f32x4{x[4], x[5], x[6], x[7]};
+      } else {
+        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(c_base) + (int64_t)m * p.ldc + n0) = pack8(x);
+      }
+    }
+  }
+}
+
+// Slow path: N not a multiple of 8 (the 4-channel UNet output, the 3-channel decoder output).
+__device__ __forceinline__ void epilogue_tail(const TcGemmParams& p, const float* cs, int tid, int tile_m, int tile_n,
+                                           int64_t bz) {
+  const bf16_t* res_base = p.residual ? reinterpret_cast<const bf16_t*>(p.residual) + bz * p.stride_c : nullptr;
+  char* c_base = reinterpret_cast<char*>(p.c) + bz * p.stride_c * (p.out_f32 ? 4 : 2);
+  for (int v = tid; v < BM * BN; v += 256) {
+    const int row = v / BN, col = v - row * BN;
+    const int m = tile_m * BM + row, n = tile_n * BN + col;
+    if (m >= p.m || n >= p.n) continue;
+    float val = cs[row * BN + col] * p.alpha;
+    if (p.bias) val += p.bias[n];
+    if (p.row_bias) val += p.row_bias[(int64_t)(m / p.row_div) * p.ldrb + n];
+    val = apply_act(val, p.act) * p.out_scale;
+    if (res_base) val += (float)res_base[(int64_t)m * p.ldr + n];
+    if (p.out_f32) reinterpret_cast<float*>(c_base)[(int64_t)m * p.ldc + n] = val;
+    else reinterpret_cast<bf16_t*>(c_base)[(int64_t)m * p.ldc + n] = (bf16_t)val;
+  }
 }
 
 template <int GATHER>
@@ -52,48 +176,47 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams p) {
   const int lrow = tid >> 3;
   const int chunk = tid & 7;
   const int hw = p.h_out * p.w_out;
-  int a_m[4];
-  bool a_ok[4];
-  int a_f[4], a_y[4], a_x[4];  // frame / y / x (CONV3x3) or t-in-clip in a_y (CONVT3)
+  bool a_ok[4], b_ok[4];
+  int a_m[4];                       // clamped output row
+  int a_f[4], a_y[4], a_x[4];       // frame / y / x (CONV3x3) or t-in-clip in a_y (CONVT3)
+  const bf16_t* b_ptr[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = tile_m * BM + lrow + 32 * i;
-    a_m[i] = m;
     a_ok[i] = m < p.m;
+    const int mc = a_ok[i] ? m : p.m - 1;
+    a_m[i] = mc;
     a_f[i] = a_y[i] = a_x[i] = 0;
     if (GATHER == TC_GATHER_CONV3x3) {
-      const int q = m / p.w_out;
-      a_x[i] = m - q * p.w_out;
+      const int q = mc / p.w_out;
+      a_x[i] = mc - q * p.w_out;
       a_f[i] = q / p.h_out;
       a_y[i] = q - a_f[i] * p.h_out;
     } else if (GATHER == TC_GATHER_CONVT3) {
-      const int f = m / hw;
-      a_y[i] = f % p.t_len;
+      a_y[i] = (mc / hw) % p.t_len;
     }
+    const int n = tile_n * BN + lrow + 32 * i;
+    b_ok[i] = n < p.n;
+    b_ptr[i] = w_base + (int64_t)(b_ok[i] ? n : p.n - 1) * p.ldw;
   }
   const int hv = p.upsample ? p.h_in * 2 : p.h_in;
   const int wv = p.upsample ? p.w_in * 2 : p.w_in;
 
   u32x4 ra[4], rb[4];
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
   auto load_tile = [&](int kb) {
     const int k0 = kb * BK;
-    const int kc = k0 + chunk * 8;
-    const bool k_ok = kc < p.k;
+    const bool k_ok = k0 + chunk * 8 < p.k;
+    const int kc = k_ok ? k0 + chunk * 8 : 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int n = tile_n * BN + lrow + 32 * i;
-      rb[i] = (k_ok && n < p.n)
-                  ? *reinterpret_cast<const u32x4*>(w_base + (int64_t)n * p.ldw + kc)
-                  : zero4;
-    }
+    for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + kc);
+    bool ok[4];
     if (GATHER == TC_GATHER_LINEAR) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        ra[i] = (k_ok && a_ok[i])
-                    ? *reinterpret_cast<const u32x4*>(a_base + (int64_t)a_m[i] * p.lda + kc)
-                    : zero4;
+      for (int i = 0; i < 4; ++i) {
+        ra[i] = *reinterpret_cast<const u32x4*>(a_base + (int64_t)a_m[i] * p.lda + kc);
+        ok[i] = a_ok[i];
+      }
     } else if (GATHER == TC_GATHER_CONV3x3) {
       const int tap = k0 / p.cin;
       const int c0 = k0 - tap * p.cin + chunk * 8;
@@ -102,10 +225,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams p) {
       for (int i = 0; i < 4; ++i) {
         int iy = a_y[i] * p.stride + dy;
         int ix = a_x[i] * p.stride + dx;
-        const bool ok = a_ok[i] && iy >= 0 && iy < hv && ix >= 0 && ix < wv;
+        ok[i] = a_ok[i] && iy >= 0 && iy < hv && ix >= 0 && ix < wv;
+        iy = ok[i] ? iy : 0;
+        ix = ok[i] ? ix : 0;
         if (p.upsample) { iy >>= 1; ix >>= 1; }
         const int64_t src = ((int64_t)a_f[i] * p.h_in + iy) * p.w_in + ix;
-        ra[i] = ok ? *reinterpret_cast<const u32x4*>(a_base + src * p.lda + c0) : zero4;
+        ra[i] = *reinterpret_cast<const u32x4*>(a_base + src * p.lda + c0);
       }
     } else {  // CONVT3
       const int tap = k0 / p.cin;
@@ -114,10 +239,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int tt = a_y[i] + dt;
-        const bool ok = a_ok[i] && tt >= 0 && tt < p.t_len;
-        const int64_t src = (int64_t)a_m[i] + (int64_t)dt * hw;
-        ra[i] = ok ? *reinterpret_cast<const u32x4*>(a_base + src * p.lda + c0) : zero4;
+        ok[i] = a_ok[i] && tt >= 0 && tt < p.t_len;
+        const int64_t src = (int64_t)a_m[i] + (ok[i] ? (int64_t)dt * hw : 0);
+        ra[i] = *reinterpret_cast<const u32x4*>(a_base + src * p.lda + c0);
       }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = mask4(ra[i], ok[i] && k_ok);
+      rb[i] = mask4(rb[i], b_ok[i] && k_ok);
     }
   };
 
@@ -190,90 +320,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams p) {
       }
   __syncthreads();
 
-  const bool geglu = p.act == TC_ACT_GEGLU;
-  const int groups = geglu ? 8 : 16;          // 8-column groups per output row of this tile
-  const int n_out = geglu ? p.n / 2 : p.n;    // logical output columns
-  const int col_tile0 = geglu ? tile_n * 64 : tile_n * BN;
-  char* c_base = reinterpret_cast<char*>(p.c) + bz * p.stride_c * (p.out_f32 ? 4 : 2);
-  const bool vec_ok = (n_out & 7) == 0;
-
-  for (int v = tid; v < BM * groups; v += 256) {
-    const int row = v / groups;
-    const int g = v - row * groups;
-    const int m = tile_m * BM + row;
-    const int n0 = col_tile0 + g * 8;
-    if (m >= p.m || n0 >= n_out) continue;
-    float x[8];
-    {
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(cs + row * BN + g * 8);
-      const f32x4 hi = *reinterpret_cast<const f32x4*>(cs + row * BN + g * 8 + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { x[e] = lo[e]; x[4 + e] = hi[e]; }
-    }
-    if (geglu) {
-      float gt[8];
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(cs + row * BN + 64 + g * 8);
-      const f32x4 hi = *reinterpret_cast<const f32x4*>(cs + row * BN + 64 + g * 8 + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { gt[e] = lo[e]; gt[4 + e] = hi[e]; }
-      const int bn = tile_n * BN + g * 8;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float val = x[e] * p.alpha, gate = gt[e] * p.alpha;
-        if (p.bias) { val += p.bias[bn + e]; gate += p.bias[bn + 64 + e]; }
-        x[e] = val * gelu_erf_f(gate) * p.out_scale;
-      }
-    } else {
-      const float* rbp = p.row_bias ? p.row_bias + (int64_t)(m / p.row_div) * p.ldrb : nullptr;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        if (n0 + e < n_out) {
-          float val = x[e] * p.alpha;
-          if (p.bias) val += p.bias[n0 + e];
-          if (rbp) val += rbp[n0 + e];
-          if (p.act == TC_ACT_SILU) val = silu_f(val);
-          else if (p.act == TC_ACT_GELU) val = gelu_erf_f(val);
-          x[e] = val * p.out_scale;
-        }
-      }
-    }
-    if (p.residual) {
-      const bf16_t* rp = reinterpret_cast<const bf16_t*>(p.residual) + bz * p.stride_c + (int64_t)m * p.ldr + n0;
-      if (vec_ok) {
-        float rf[8];
-        unpack8(*reinterpret_cast<const u32x4*>(rp), rf);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] += rf[e];
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (n0 + e < n_out) x[e] += (float)rp[e];
-      }
-    }
-    if (p.out_f32) {
-      float* op = reinterpret_cast<float*>(c_base) + (int64_t)m * p.ldc + n0;
-      if (vec_ok) {
-        f32x4 lo, hi;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { lo[e] = x[e]; hi[e] = x[4 + e]; }
-        *reinterpret_cast<f32x4*>(op) = lo;
-        *reinterpret_cast<f32x4*>(op + 4) = hi;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (n0 + e < n_out) op[e] = x[e];
-      }
-    } else {
-      bf16_t* op = reinterpret_cast<bf16_t*>(c_base) + (int64_t)m * p.ldc + n0;
-      if (vec_ok) {
-        *reinterpret_cast<u32x4*>(op) = pack8(x);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (n0 + e < n_out) op[e] = (bf16_t)x[e];
-      }
-    }
-  }
+  const int n_out = p.act == TC_ACT_GEGLU ? p.n / 2 : p.n;
+  if ((n_out & 7) != 0) epilogue_tail(p, cs, tid, tile_m, tile_n, bz);
+  else if (p.act == TC_ACT_GEGLU) epilogue_fast<true>(p, cs, tid, tile_m, tile_n, bz);
+  else epilogue_fast<false>(p, cs, tid, tile_m, tile_n, bz);
 }
 
 }  // namespace
@@ -291,6 +341,8 @@ extern "C" int tc_gemm_bf16(const TcGemmParams* pp, void* stream) {
   if ((n_out & 7) == 0) {
     if (p.out_f32 ? (p.ldc & 3) : (p.ldc & 7)) return TC_EALIGN;
     if (p.residual && (p.ldr & 7)) return TC_EALIGN;
+    if (p.bias && (reinterpret_cast<uintptr_t>(p.bias) & 15u)) return TC_EALIGN;
+    if (p.row_bias && ((reinterpret_cast<uintptr_t>(p.row_bias) & 15u) || (p.ldrb & 3))) return TC_EALIGN;
   }
   if (p.ldc < n_out || (p.residual && p.ldr < n_out)) return TC_ESHAPE;
   if (geglu && ((p.n % 128) != 0 || p.row_bias || p.residual)) return TC_ESHAPE;

@@ -1,14 +1,18 @@
 // GroupNorm(32) (+SiLU), LayerNorm and row softmax over channels-last bf16 rows, gfx950.
 // All three are HBM-bound: 16-byte vector loads/stores, fp32 statistics, wave64 shuffles.
 //
-// GroupNorm is two launches:
-//   gn_stats : grid (chunks, samples).  A block walks its chunk of rows with every thread
-//              pinned to one 8-channel vector (so per-channel sums stay in registers), then
-//              folds channels -> groups through LDS and writes one (sum, sumsq) pair per
-//              (sample, chunk, group).  Deterministic: no atomics.
-//   gn_apply : same decomposition; the prologue reduces the per-chunk partials of its sample
-//              to mean / rstd, folds them with gamma/beta into per-channel (scale, shift)
-//              registers, then streams y = silu(x * scale + shift).
+// GroupNorm is three launches:
+//   gn_stats    : grid (chunks, samples).  A block walks its chunk of rows with every thread
+//                 pinned to one 8-channel vector (so per-channel sums stay in registers, four
+//                 row loads in flight per thread), folds channels -> groups through LDS and
+//                 writes one (sum, sumsq) pair per (sample, chunk, group).  No atomics:
+//                 bit-reproducible.
+//   gn_finalize : grid (samples).  256 threads reduce the per-chunk partials of the 32 groups
+//                 (8 lanes per group + shuffles) to (mean, rstd).
+//   gn_apply    : same decomposition as gn_stats; folds mean/rstd with gamma/beta into
+//                 per-channel (scale, shift) registers and streams y = silu(x * scale + shift).
+// The chunk height is chosen on the host so that ~2048 blocks are in flight whatever the
+// tensor shape (clip-wide statistics have only B samples, per-frame ones B*T).
 // Algorithmic traffic: read x twice, write y once (the second read mostly hits the 256 MiB
 // Infinity Cache for UNet-sized tensors).
 #include "common.h"
@@ -17,7 +21,8 @@ namespace {
 
 constexpr int GN_THREADS = 256;
 constexpr int GN_MAX_SLOTS = 2;       // 8-channel vectors per thread per row pass -> C <= 4096
-constexpr int GN_ROWS_PER_CHUNK = 512;
+constexpr int GN_TARGET_BLOCKS = 2048;
+constexpr int GN_MIN_ROWS = 8;
 
 struct GnGeo {
   int vpr;         // 8-channel vectors per row (C/8)
@@ -25,7 +30,7 @@ struct GnGeo {
   int rows_pp;     // rows processed per pass by one block
 };
 
-__device__ __forceinline__ GnGeo gn_geo(int c) {
+__host__ __device__ __forceinline__ GnGeo gn_geo(int c) {
   GnGeo g;
   g.vpr = c >> 3;
   g.slots = (g.vpr + GN_THREADS - 1) / GN_THREADS;
@@ -35,7 +40,7 @@ __device__ __forceinline__ GnGeo gn_geo(int c) {
   return g;
 }
 
-// thread -> (row lane, vector index for slot s); returns -1 when idle
+// thread -> (row lane, vector index for slot s); -1 when idle
 __device__ __forceinline__ void gn_thread_map(const GnGeo& g, int tid, int& rlane, int (&vec)[GN_MAX_SLOTS]) {
   if (g.slots > 1) {
     rlane = 0;
@@ -53,15 +58,15 @@ __device__ __forceinline__ void gn_thread_map(const GnGeo& g, int tid, int& rlan
 }
 
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ part,
-                                                              int rows, int c, int nchunks) {
+                                                              int rows, int c, int nchunks, int chunk_rows) {
   __shared__ float red[2][4096 + 32];
   const GnGeo g = gn_geo(c);
   const int tid = threadIdx.x;
   int rlane, vec[GN_MAX_SLOTS];
   gn_thread_map(g, tid, rlane, vec);
   const int sample = blockIdx.y, chunk = blockIdx.x;
-  const int r0 = chunk * GN_ROWS_PER_CHUNK;
-  const int r1 = min(rows, r0 + GN_ROWS_PER_CHUNK);
+  const int r0 = chunk * chunk_rows;
+  const int r1 = min(rows, r0 + chunk_rows);
   const bf16_t* xs = x + (int64_t)sample * rows * c;
 
   float sum[GN_MAX_SLOTS][8], sq[GN_MAX_SLOTS][8];
@@ -70,18 +75,29 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16_t* __re
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sum[s][e] = 0.f; sq[s][e] = 0.f; }
 
-  for (int r = r0 + rlane; r < r1; r += g.rows_pp) {
+  const int step = g.rows_pp;
+  for (int r = r0 + rlane; r < r1; r += 4 * step) {
 #pragma unroll
     for (int s = 0; s < GN_MAX_SLOTS; ++s) {
       if (vec[s] >= 0) {
-        float f[8];
-        unpack8(*reinterpret_cast<const u32x4*>(xs + (int64_t)r * c + vec[s] * 8), f);
+        u32x4 v4[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { sum[s][e] += f[e]; sq[s][e] += f[e] * f[e]; }
+        for (int u = 0; u < 4; ++u) {
+          const int rr = r + u * step;
+          v4[u] = rr < r1 ? *reinterpret_cast<const u32x4*>(xs + (int64_t)rr * c + vec[s] * 8)
+                          : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float f[8];
+          unpack8(v4[u], f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { sum[s][e] += f[e]; sq[s][e] += f[e] * f[e]; }
+        }
       }
     }
   }
-  // fold row lanes: per-channel totals in LDS (row lane 0 initialises, others add in turn)
+  // fold row lanes: per-channel totals in LDS (row lane 0 initialises, the others add in turn)
   for (int pass = 0; pass < g.rows_pp; ++pass) {
     if (rlane == pass) {
 #pragma unroll
@@ -107,28 +123,36 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16_t* __re
   }
 }
 
+// part: [samples][nchunks][32][2] -> stats: [samples][32][2] = (mean, rstd)
+__global__ __launch_bounds__(GN_THREADS) void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats,
+                                                                 int rows, int c, int nchunks, float eps) {
+  const int sample = blockIdx.x;
+  const int grp = threadIdx.x >> 3, sub = threadIdx.x & 7;
+  double a = 0.0, b = 0.0;
+  const float* pp = part + ((int64_t)sample * nchunks * 32 + grp) * 2;
+  for (int k = sub; k < nchunks; k += 8) { a += pp[(int64_t)k * 64]; b += pp[(int64_t)k * 64 + 1]; }
+#pragma unroll
+  for (int off = 1; off < 8; off <<= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
+  if (sub == 0) {
+    const double cnt = (double)rows * (c / 32);
+    const double mean = a / cnt;
+    double var = b / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[((int64_t)sample * 32 + grp) * 2] = (float)mean;
+    stats[((int64_t)sample * 32 + grp) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              const float* __restrict__ part, int rows, int c, int nchunks,
-                                                              float eps, int silu) {
-  __shared__ float mean_s[32], rstd_s[32];
+                                                              const float* __restrict__ stats, int rows, int c,
+                                                              int chunk_rows, int silu) {
   const GnGeo g = gn_geo(c);
   const int tid = threadIdx.x;
   int rlane, vec[GN_MAX_SLOTS];
   gn_thread_map(g, tid, rlane, vec);
   const int sample = blockIdx.y, chunk = blockIdx.x;
-  if (tid < 32) {
-    double a = 0.0, b = 0.0;
-    const float* pp = part + ((int64_t)sample * nchunks * 32 + tid) * 2;
-    for (int k = 0; k < nchunks; ++k) { a += pp[(int64_t)k * 64]; b += pp[(int64_t)k * 64 + 1]; }
-    const double cnt = (double)rows * (c / 32);
-    const double mean = a / cnt;
-    double var = b / cnt - mean * mean;
-    if (var < 0.0) var = 0.0;
-    mean_s[tid] = (float)mean;
-    rstd_s[tid] = (float)(1.0 / sqrt(var + (double)eps));
-  }
-  __syncthreads();
+  const float* st = stats + (int64_t)sample * 64;
   const int cpg = c / 32;
   float sc[GN_MAX_SLOTS][8], sh[GN_MAX_SLOTS][8];
 #pragma unroll
@@ -139,28 +163,40 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __re
       if (vec[s] >= 0) {
         const int ch = vec[s] * 8 + e;
         const int grp = ch / cpg;
-        const float a = rstd_s[grp] * gamma[ch];
+        const float a = st[grp * 2 + 1] * gamma[ch];
         sc[s][e] = a;
-        sh[s][e] = beta[ch] - mean_s[grp] * a;
+        sh[s][e] = beta[ch] - st[grp * 2] * a;
       }
     }
-  const int r0 = chunk * GN_ROWS_PER_CHUNK;
-  const int r1 = min(rows, r0 + GN_ROWS_PER_CHUNK);
+  const int r0 = chunk * chunk_rows;
+  const int r1 = min(rows, r0 + chunk_rows);
   const bf16_t* xs = x + (int64_t)sample * rows * c;
   bf16_t* ys = y + (int64_t)sample * rows * c;
-  for (int r = r0 + rlane; r < r1; r += g.rows_pp) {
+  const int step = g.rows_pp;
+  for (int r = r0 + rlane; r < r1; r += 4 * step) {
 #pragma unroll
     for (int s = 0; s < GN_MAX_SLOTS; ++s) {
       if (vec[s] >= 0) {
-        const int64_t off = (int64_t)r * c + vec[s] * 8;
-        float f[8];
-        unpack8(*reinterpret_cast<const u32x4*>(xs + off), f);
+        u32x4 v4[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float v = f[e] * sc[s][e] + sh[s][e];
-          f[e] = silu ? silu_f(v) : v;
+        for (int u = 0; u < 4; ++u) {
+          const int rr = r + u * step;
+          if (rr < r1) v4[u] = *reinterpret_cast<const u32x4*>(xs + (int64_t)rr * c + vec[s] * 8);
         }
-        *reinterpret_cast<u32x4*>(ys + off) = pack8(f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int rr = r + u * step;
+          if (rr < r1) {
+            float f[8];
+            unpack8(v4[u], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float v = f[e] * sc[s][e] + sh[s][e];
+              f[e] = silu ? silu_f(v) : v;
+            }
+            *reinterpret_cast<u32x4*>(ys + (int64_t)rr * c + vec[s] * 8) = pack8(f);
+          }
+        }
       }
     }
   }
@@ -245,12 +281,24 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 
 }  // namespace
 
-static inline int gn_chunks(int rows) { return (rows + GN_ROWS_PER_CHUNK - 1) / GN_ROWS_PER_CHUNK; }
+// chunk height: ~GN_TARGET_BLOCKS blocks in flight, at least GN_MIN_ROWS rows each
+static inline void gn_chunking(int samples, int rows, int* nchunks, int* chunk_rows) {
+  int per_sample = GN_TARGET_BLOCKS / (samples > 0 ? samples : 1);
+  if (per_sample < 1) per_sample = 1;
+  int max_chunks = (rows + GN_MIN_ROWS - 1) / GN_MIN_ROWS;
+  int n = per_sample < max_chunks ? per_sample : max_chunks;
+  if (n < 1) n = 1;
+  const int cr = (rows + n - 1) / n;
+  *chunk_rows = cr;
+  *nchunks = (rows + cr - 1) / cr;
+}
 
 extern "C" int64_t tc_groupnorm_workspace(int32_t samples, int32_t rows, int32_t c) {
   (void)c;
   if (samples <= 0 || rows <= 0) return 0;
-  return (int64_t)samples * gn_chunks(rows) * 32 * 2 * sizeof(float);
+  int nch, cr;
+  gn_chunking(samples, rows, &nch, &cr);
+  return ((int64_t)samples * nch * 64 + (int64_t)samples * 64) * sizeof(float);
 }
 
 extern "C" int tc_groupnorm(const tc_bf16* x, tc_bf16* y, const float* gamma, const float* beta,
@@ -262,15 +310,18 @@ extern "C" int tc_groupnorm(const tc_bf16* x, tc_bf16* y, const float* gamma, co
   if (!tc_aligned16(x) || !tc_aligned16(y)) return TC_EALIGN;
   if (workspace_bytes < tc_groupnorm_workspace(samples, rows, c)) return TC_EWORKSPACE;
   if (samples > 65535) return TC_ESHAPE;
-  const int nch = gn_chunks(rows);
+  int nch, cr;
+  gn_chunking(samples, rows, &nch, &cr);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  float* part = reinterpret_cast<float*>(workspace);
+  float* stats = part + (int64_t)samples * nch * 64;
   dim3 grid(nch, samples), block(GN_THREADS);
-  hipLaunchKernelGGL(gn_stats_kernel, grid, block, 0, s, reinterpret_cast<const bf16_t*>(x),
-                     reinterpret_cast<float*>(workspace), rows, c, nch);
+  hipLaunchKernelGGL(gn_stats_kernel, grid, block, 0, s, reinterpret_cast<const bf16_t*>(x), part, rows, c, nch, cr);
+  TC_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(samples), block, 0, s, part, stats, rows, c, nch, eps);
   TC_LAUNCH_CHECK();
   hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, s, reinterpret_cast<const bf16_t*>(x),
-                     reinterpret_cast<bf16_t*>(y), gamma, beta, reinterpret_cast<const float*>(workspace), rows, c,
-                     nch, eps, silu);
+                     reinterpret_cast<bf16_t*>(y), gamma, beta, stats, rows, c, cr, silu);
   TC_LAUNCH_CHECK();
   return TC_OK;
 }
