@@ -23,8 +23,10 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int STAGE_BYTES = (BM + BN) * BK * 2;  // 32 KiB per stage
+constexpr int BK = 64;
+// Tile = (64*TM) x (64*TN): 4 waves as 2x2, each wave (32*TM) x (32*TN) = TM x TN MFMA sub-tiles.
+// 128x128 (TM=TN=2) is the workhorse; 64x64 (TM=TN=1) quadruples the block count for the
+// low-resolution layers whose 128-tiles would not fill the 256 CUs.
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4);
@@ -43,16 +45,16 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 // ---- epilogue over the fp32 tile staged in LDS ----------------------------------------
 // Fast path: every 8-column vector of the tile is fully inside N and 16-byte addressable.
-template <bool GEGLU>
+template <bool GEGLU, int BM, int BN>
 __device__ __forceinline__ void epilogue_fast(const TcGemmParams& p, const float* cs, int tid, int tile_m, int tile_n,
                                               int64_t bz) {
-  constexpr int GROUPS = GEGLU ? 8 : 16;       // 8-column groups per output row of this tile
-  constexpr int ITERS = BM * GROUPS / 256;     // 4 or 8
-  constexpr int ROWS_PER_IT = 256 / GROUPS;    // 32 or 16
+  constexpr int GROUPS = GEGLU ? BN / 16 : BN / 8;   // 8-column groups per output row of this tile
+  constexpr int ITERS = BM * GROUPS / 256;
+  constexpr int ROWS_PER_IT = 256 / GROUPS;
   const int g = tid % GROUPS;
   const int row0 = tid / GROUPS;
   const int n_out = GEGLU ? p.n / 2 : p.n;
-  const int n0 = (GEGLU ? tile_n * 64 : tile_n * BN) + g * 8;
+  const int n0 = (GEGLU ? tile_n * (BN / 2) : tile_n * BN) + g * 8;
   if (n0 >= n_out) return;
   float bv[8], bg[8];
 #pragma unroll
@@ -63,7 +65,7 @@ __device__ __forceinline__ void epilogue_fast(const TcGemmParams& p, const float
 #pragma unroll
     for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
     if (GEGLU) {
-      const f32x4 g0 = *reinterpret_cast<const f32x4*>(bp + 64), g1 = *reinterpret_cast<const f32x4*>(bp + 68);
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(bp + BN / 2), g1 = *reinterpret_cast<const f32x4*>(bp + BN / 2 + 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { bg[e] = g0[e]; bg[4 + e] = g1[e]; }
     }
@@ -99,8 +101,8 @@ __device__ __forceinline__ void epilogue_fast(const TcGemmParams& p, const float
       for (int e = 0; e < 4; ++e) { x[e] = lo[e]; x[4 + e] = hi[e]; }
     }
     if (GEGLU) {
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(cs + row * BN + 64 + g * 8);
-      const f32x4 hi = *reinterpret_cast<const f32x4*>(cs + row * BN + 64 + g * 8 + 4);
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(cs + row * BN + BN / 2 + g * 8);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(cs + row * BN + BN / 2 + g * 8 + 4);
       float gt[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) { gt[e] = lo[e]; gt[4 + e] = hi[e]; }
@@ -133,8 +135,9 @@ __device__ __forceinline__ void epilogue_fast(const TcGemmParams& p, const float
 }
 
 // Slow path: N not a multiple of 8 (the 4-channel UNet output, the 3-channel decoder output).
+template <int BM, int BN>
 __device__ __forceinline__ void epilogue_tail(const TcGemmParams& p, const float* cs, int tid, int tile_m, int tile_n,
-                                           int64_t bz) {
+                                              int64_t bz) {
   const bf16_t* res_base = p.residual ? reinterpret_cast<const bf16_t*>(p.residual) + bz * p.stride_c : nullptr;
   char* c_base = reinterpret_cast<char*>(p.c) + bz * p.stride_c * (p.out_f32 ? 4 : 2);
   for (int v = tid; v < BM * BN; v += 256) {
@@ -151,9 +154,14 @@ __device__ __forceinline__ void epilogue_tail(const TcGemmParams& p, const float
   }
 }
 
-template <int GATHER>
+template <int GATHER, int TM, int TN>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];  // 64 KiB; reused by the epilogue
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int STAGE_BYTES = (BM + BN) * BK * 2;                       // 32 KiB per stage at 128x128
+  constexpr int EPI_BYTES = BM * BN * 4;
+  constexpr int SMEM_BYTES = 2 * STAGE_BYTES > EPI_BYTES ? 2 * STAGE_BYTES : EPI_BYTES;
+  constexpr int RA = BM / 32, RB = BN / 32;                             // loader rows per thread
+  __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];       // reused by the epilogue
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -176,12 +184,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams p) {
   const int lrow = tid >> 3;
   const int chunk = tid & 7;
   const int hw = p.h_out * p.w_out;
-  bool a_ok[4], b_ok[4];
-  int a_m[4];                       // clamped output row
-  int a_f[4], a_y[4], a_x[4];       // frame / y / x (CONV3x3) or t-in-clip in a_y (CONVT3)
-  const bf16_t* b_ptr[4];
+  bool a_ok[RA], b_ok[RB];
+  int a_m[RA];                      // clamped output row
+  int a_f[RA], a_y[RA], a_x[RA];    // frame / y / x (CONV3x3) or t-in-clip in a_y (CONVT3)
+  const bf16_t* b_ptr[RB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < RA; ++i) {
     const int m = tile_m * BM + lrow + 32 * i;
     a_ok[i] = m < p.m;
     const int mc = a_ok[i] ? m : p.m - 1;
@@ -195,6 +203,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams p) {
     } else if (GATHER == TC_GATHER_CONVT3) {
       a_y[i] = (mc / hw) % p.t_len;
     }
+  }
+#pragma unroll
+  for (int i = 0; i < RB; ++i) {
     const int n = tile_n * BN + lrow + 32 * i;
     b_ok[i] = n < p.n;
     b_ptr[i] = w_base + (int64_t)(b_ok[i] ? n : p.n - 1) * p.ldw;
@@ -202,18 +213,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams p) {
   const int hv = p.upsample ? p.h_in * 2 : p.h_in;
   const int wv = p.upsample ? p.w_in * 2 : p.w_in;
 
-  u32x4 ra[4], rb[4];
+  u32x4 ra[RA], rb[RB];
 
   auto load_tile = [&](int kb) {
     const int k0 = kb * BK;
     const bool k_ok = k0 + chunk * 8 < p.k;
     const int kc = k_ok ? k0 + chunk * 8 : 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + kc);
-    bool ok[4];
+    for (int i = 0; i < RB; ++i) rb[i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + kc);
+    bool ok[RA];
     if (GATHER == TC_GATHER_LINEAR) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < RA; ++i) {
         ra[i] = *reinterpret_cast<const u32x4*>(a_base + (int64_t)a_m[i] * p.lda + kc);
         ok[i] = a_ok[i];
       }
@@ -222,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams p) {
       const int c0 = k0 - tap * p.cin + chunk * 8;
       const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < RA; ++i) {
         int iy = a_y[i] * p.stride + dy;
         int ix = a_x[i] * p.stride + dx;
         ok[i] = a_ok[i] && iy >= 0 && iy < hv && ix >= 0 && ix < wv;
@@ -237,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams p) {
       const int c0 = k0 - tap * p.cin + chunk * 8;
       const int dt = tap - 1;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < RA; ++i) {
         const int tt = a_y[i] + dt;
         ok[i] = a_ok[i] && tt >= 0 && tt < p.t_len;
         const int64_t src = (int64_t)a_m[i] + (ok[i] ? (int64_t)dt * hw : 0);
@@ -245,28 +256,25 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams p) {
       }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ra[i] = mask4(ra[i], ok[i] && k_ok);
-      rb[i] = mask4(rb[i], b_ok[i] && k_ok);
-    }
+    for (int i = 0; i < RA; ++i) ra[i] = mask4(ra[i], ok[i] && k_ok);
+#pragma unroll
+    for (int i = 0; i < RB; ++i) rb[i] = mask4(rb[i], b_ok[i] && k_ok);
   };
 
   auto store_tile = [&](int stage) {
     char* sa = smem + stage * STAGE_BYTES;
     char* sb = sa + BM * BK * 2;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int off = lds_off(lrow + 32 * i, chunk);
-      *reinterpret_cast<u32x4*>(sa + off) = ra[i];
-      *reinterpret_cast<u32x4*>(sb + off) = rb[i];
-    }
+    for (int i = 0; i < RA; ++i) *reinterpret_cast<u32x4*>(sa + lds_off(lrow + 32 * i, chunk)) = ra[i];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) *reinterpret_cast<u32x4*>(sb + lds_off(lrow + 32 * i, chunk)) = rb[i];
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -279,17 +287,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams p) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int c = kk * 2 + fhalf;
-      bf16x8 af[2], bf[2];
+      bf16x8 af[TM], bf[TN];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        af[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(wm * 64 + i * 32 + frow, c));
+      for (int i = 0; i < TM; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(wm * 32 * TM + i * 32 + frow, c));
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        bf[j] = *reinterpret_cast<const bf16x8*>(sb + lds_off(wn * 64 + j * 32 + frow, c));
+      for (int j = 0; j < TN; ++j)
+        bf[j] = *reinterpret_cast<const bf16x8*>(sb + lds_off(wn * 32 * TN + j * 32 + frow, c));
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
   };
@@ -306,24 +314,24 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue: accumulators -> LDS fp32 [128][128] -> row vectors
+  // ---- epilogue: accumulators -> LDS fp32 [BM][BN] -> row vectors
   float* cs = reinterpret_cast<float*>(smem);
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-        const int col = wn * 64 + j * 32 + frow;
+        const int row = wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+        const int col = wn * 32 * TN + j * 32 + frow;
         cs[row * BN + col] = acc[i][j][r];
       }
   __syncthreads();
 
   const int n_out = p.act == TC_ACT_GEGLU ? p.n / 2 : p.n;
-  if ((n_out & 7) != 0) epilogue_tail(p, cs, tid, tile_m, tile_n, bz);
-  else if (p.act == TC_ACT_GEGLU) epilogue_fast<true>(p, cs, tid, tile_m, tile_n, bz);
-  else epilogue_fast<false>(p, cs, tid, tile_m, tile_n, bz);
+  if ((n_out & 7) != 0) epilogue_tail<BM, BN>(p, cs, tid, tile_m, tile_n, bz);
+  else if (TN == 2 && p.act == TC_ACT_GEGLU) epilogue_fast<true, BM, BN>(p, cs, tid, tile_m, tile_n, bz);
+  else epilogue_fast<false, BM, BN>(p, cs, tid, tile_m, tile_n, bz);
 }
 
 }  // namespace
@@ -367,17 +375,27 @@ extern "C" int tc_gemm_bf16(const TcGemmParams* pp, void* stream) {
   } else {
     return TC_EINVAL;
   }
-  const int tiles_n = (p.n + BN - 1) / BN;
-  const int tiles_m = (p.m + BM - 1) / BM;
+  // tile choice: 128x128 unless that leaves most of the 256 CUs idle (low-resolution layers)
+  const int64_t big_tiles = (int64_t)((p.n + 127) / 128) * ((p.m + 127) / 128) * batch;
+  const bool small = !geglu && big_tiles < 384;
+  const int bm = small ? 64 : 128, bn = small ? 64 : 128;
+  const int tiles_n = (p.n + bn - 1) / bn;
+  const int tiles_m = (p.m + bm - 1) / bm;
   const int64_t nblk = (int64_t)tiles_n * 8 * ((tiles_m + 7) / 8);
   if (nblk > 0x7fffffffLL || batch > 65535) return TC_ESHAPE;
   dim3 grid((unsigned)nblk, 1, (unsigned)batch), block(256);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define TC_LAUNCH_GEMM(G)                                                              \
+  do {                                                                                 \
+    if (small) hipLaunchKernelGGL((gemm_kernel<G, 1, 1>), grid, block, 0, s, p);       \
+    else hipLaunchKernelGGL((gemm_kernel<G, 2, 2>), grid, block, 0, s, p);             \
+  } while (0)
   switch (p.gather) {
-    case TC_GATHER_LINEAR: hipLaunchKernelGGL(gemm_kernel<TC_GATHER_LINEAR>, grid, block, 0, s, p); break;
-    case TC_GATHER_CONV3x3: hipLaunchKernelGGL(gemm_kernel<TC_GATHER_CONV3x3>, grid, block, 0, s, p); break;
-    default: hipLaunchKernelGGL(gemm_kernel<TC_GATHER_CONVT3>, grid, block, 0, s, p); break;
+    case TC_GATHER_LINEAR: TC_LAUNCH_GEMM(TC_GATHER_LINEAR); break;
+    case TC_GATHER_CONV3x3: TC_LAUNCH_GEMM(TC_GATHER_CONV3x3); break;
+    default: TC_LAUNCH_GEMM(TC_GATHER_CONVT3); break;
   }
+#undef TC_LAUNCH_GEMM
   TC_LAUNCH_CHECK();
   return TC_OK;
 }

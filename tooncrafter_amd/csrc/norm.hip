@@ -123,23 +123,30 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16_t* __re
   }
 }
 
-// part: [samples][nchunks][32][2] -> stats: [samples][32][2] = (mean, rstd)
-__global__ __launch_bounds__(GN_THREADS) void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats,
-                                                                 int rows, int c, int nchunks, float eps) {
-  const int sample = blockIdx.x;
-  const int grp = threadIdx.x >> 3, sub = threadIdx.x & 7;
-  double a = 0.0, b = 0.0;
+// part: [samples][nchunks][32][2] -> stats: [samples][32][2] = (mean, rstd).
+// One wave per (sample, group): 64 lanes stride over the chunks, then a wave reduction.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats,
+                                                          int samples, int rows, int c, int nchunks, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int sg = blockIdx.x * 4 + (threadIdx.x >> 6);        // sample*32 + group
+  if (sg >= samples * 32) return;
+  const int sample = sg >> 5, grp = sg & 31;
   const float* pp = part + ((int64_t)sample * nchunks * 32 + grp) * 2;
-  for (int k = sub; k < nchunks; k += 8) { a += pp[(int64_t)k * 64]; b += pp[(int64_t)k * 64 + 1]; }
+  double a = 0.0, b = 0.0;
+  for (int k = lane; k < nchunks; k += 64) {
+    const float2 v = *reinterpret_cast<const float2*>(pp + (int64_t)k * 64);
+    a += v.x;
+    b += v.y;
+  }
 #pragma unroll
-  for (int off = 1; off < 8; off <<= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
-  if (sub == 0) {
+  for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
+  if (lane == 0) {
     const double cnt = (double)rows * (c / 32);
     const double mean = a / cnt;
     double var = b / cnt - mean * mean;
     if (var < 0.0) var = 0.0;
-    stats[((int64_t)sample * 32 + grp) * 2] = (float)mean;
-    stats[((int64_t)sample * 32 + grp) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    stats[(int64_t)sg * 2] = (float)mean;
+    stats[(int64_t)sg * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
   }
 }
 
@@ -318,7 +325,8 @@ extern "C" int tc_groupnorm(const tc_bf16* x, tc_bf16* y, const float* gamma, co
   dim3 grid(nch, samples), block(GN_THREADS);
   hipLaunchKernelGGL(gn_stats_kernel, grid, block, 0, s, reinterpret_cast<const bf16_t*>(x), part, rows, c, nch, cr);
   TC_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(samples), block, 0, s, part, stats, rows, c, nch, eps);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((samples * 32 + 3) / 4), block, 0, s, part, stats, samples, rows, c, nch,
+                     eps);
   TC_LAUNCH_CHECK();
   hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, s, reinterpret_cast<const bf16_t*>(x),
                      reinterpret_cast<bf16_t*>(y), gamma, beta, stats, rows, c, cr, silu);

@@ -31,14 +31,15 @@ class ContextCache:
 
     `context`: (B, L, Cc) fp32.  With L == 77 + 16*T the tail is per-frame image
     tokens (reference openaimodel3d.py:556-560); otherwise both parts are shared
-    by all frames of a clip."""
+    by all frames of a clip.  The bf16 token rows and every attention block's
+    projected K/V live in buffers that are REFRESHED IN PLACE when the conditioning
+    values change, so a captured hipGraph of the UNet keeps pointing at valid data."""
 
     def __init__(self, context: torch.Tensor, t: int, text_len: int = 77):
         b, l, cc = context.shape
         self.b, self.t, self.cc = b, t, cc
-        ctx = context.detach()
+        self.shape = tuple(context.shape)
         self.text_len = min(text_len, l)
-        self.text_rows = ctx[:, :self.text_len].reshape(b * self.text_len, cc).to(torch.bfloat16).contiguous()
         li = l - self.text_len
         self.img_rows = None
         self.img_len = 0
@@ -49,9 +50,30 @@ class ContextCache:
                 self.img_len = 16
             else:
                 self.img_len = li
-            self.img_rows = ctx[:, self.text_len:].reshape(b * li, cc).to(torch.bfloat16).contiguous()
-        self.kv = {}          # id(module) -> (kv_text, kv_img)
-        self.key = (context.data_ptr(), context._version, tuple(context.shape), t)
+        self.text_rows = torch.empty((b * self.text_len, cc), dtype=torch.bfloat16, device=context.device)
+        if li > 0:
+            self.img_rows = torch.empty((b * li, cc), dtype=torch.bfloat16, device=context.device)
+        self.kv = {}          # id(module) -> (module, kv_text, kv_img)
+        self.key = None
+        self.refresh(context)
+
+    @staticmethod
+    def key_of(context: torch.Tensor):
+        return (context.data_ptr(), context._version)
+
+    def matches(self, context: torch.Tensor, t: int) -> bool:
+        return self.shape == tuple(context.shape) and self.t == t and self.text_rows.device == context.device
+
+    def refresh(self, context: torch.Tensor):
+        """(Re)load the token rows and recompute every cached K/V projection in place."""
+        ctx = context.detach()
+        b, cc = self.b, self.cc
+        self.text_rows.copy_(ctx[:, :self.text_len].reshape(b * self.text_len, cc))
+        if self.img_rows is not None:
+            self.img_rows.copy_(ctx[:, self.text_len:].reshape(-1, cc))
+        for module, kv_text, kv_img in self.kv.values():
+            module.project_context(self, kv_text, kv_img)
+        self.key = self.key_of(context)
 
 
 class GEGLU(nn.Module):
@@ -136,16 +158,19 @@ class CrossAttention(PackedModule):
         return ops.gemm(a, pk["wo"], pk["bo"], residual=residual)
 
     # -- text + image cross attention: two softmaxes, summed
+    def project_context(self, ctx: ContextCache, kv_text=None, kv_img=None):
+        pk = self.pk
+        kv_text = ops.gemm(ctx.text_rows, pk["wkv"], out=kv_text)
+        if self.image_cross_attention and ctx.img_rows is not None:
+            kv_img = ops.gemm(ctx.img_rows, pk["wkv_ip"], out=kv_img)
+        return kv_text, kv_img
+
     def context_kv(self, ctx: ContextCache):
         hit = ctx.kv.get(id(self))
         if hit is None:
-            pk = self.pk
-            kv_text = ops.gemm(ctx.text_rows, pk["wkv"])
-            kv_img = None
-            if self.image_cross_attention and ctx.img_rows is not None:
-                kv_img = ops.gemm(ctx.img_rows, pk["wkv_ip"])
-            hit = ctx.kv[id(self)] = (kv_text, kv_img)
-        return hit
+            kv_text, kv_img = self.project_context(ctx)
+            hit = ctx.kv[id(self)] = (self, kv_text, kv_img)
+        return hit[1], hit[2]
 
     def forward_cross(self, x_norm, residual, act: Act, ctx: ContextCache):
         pk = self.pk

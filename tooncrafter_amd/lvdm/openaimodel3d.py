@@ -309,10 +309,14 @@ class UNetModel(PackedModule):
 
     # ------------------------------------------------------------------ conditioning
     def context_cache(self, context: torch.Tensor, t: int) -> ContextCache:
-        key = (context.data_ptr(), context._version, tuple(context.shape), t)
-        if self._ctx_cache is None or self._ctx_cache.key != key:
-            self._ctx_cache = ContextCache(context, t)
-        return self._ctx_cache
+        """Conditioning rows + projected K/V.  Rebuilt when the shape changes, refreshed IN PLACE
+        when only the values do (same buffers, so captured hipGraphs stay valid)."""
+        c = self._ctx_cache
+        if c is None or not c.matches(context, t):
+            c = self._ctx_cache = ContextCache(context, t)
+        elif c.key != ContextCache.key_of(context):
+            c.refresh(context)
+        return c
 
     def _embedding(self, timesteps, fs, b):
         """silu(time_embed(t) + fps_embedding(fs)) pushed through every ResBlock's emb Linear:
