@@ -180,6 +180,7 @@ def cpu_baseline(model, inp):
     from oracle import unet as ounet
     un = model.model.diffusion_model
     t0 = time.time()
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
     sd = {k: v.detach().float().cpu() for k, v in un.state_dict().items()}
     x = torch.cat([inp["x_T"], inp["c_concat"]], 1).cpu()
     ts = torch.tensor([499])
@@ -208,16 +209,11 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
+    from tooncrafter_amd import dist as tcdist
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+    rank, world = tcdist.init(backend="nccl", device=device)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert ops.backend().name == "hip"
 
@@ -230,8 +226,7 @@ def main():
     def step():
         with torch.no_grad():
             video = run_clip(model, sampler, inp, args.ddim_steps)
-            if world > 1:
-                dist.gather(video, gather_buf, dst=0)
+            tcdist.gather_clips(video, dst=0, out=gather_buf)       # the one collective of the path
         return video
 
     def fence():
