@@ -52,7 +52,7 @@ typedef struct TcGemmParams {
   /* operands */
   const tc_bf16* a;        /* activations, channels-last rows */
   const tc_bf16* w;        /* [N, K] bf16; K = taps*cin, tap-major then channel; for TC_ACT_GEGLU
-                              rows are packed per 128-row block: 64 value rows then their 64 gate rows */
+                              every 32 rows are packed as 16 value rows then their 16 gate rows */
   void* c;                 /* [M, ldc] bf16 (or fp32 when out_f32) */
   const float* bias;       /* [N] fp32 or NULL (same packing as w rows) */
   const float* row_bias;   /* [ceil(M/row_div), N] fp32 or NULL: per-frame embedding add */

@@ -70,13 +70,13 @@ class EmuOps:
             A = A[:m]
         acc = (A @ _f(w).t()) * alpha
         if act == ACT_GEGLU:
-            # rows packed per 128: [64 values | 64 gates]
-            nb = n // 128
-            acc = acc.reshape(-1, nb, 2, 64)
+            # rows packed per 32: [16 values | 16 gates]
+            nb = n // 32
+            acc = acc.reshape(-1, nb, 2, 16)
             if bias is not None:
-                acc = acc + bias.reshape(nb, 2, 64)
+                acc = acc + bias.reshape(nb, 2, 16)
             v = acc[:, :, 0] * F.gelu(acc[:, :, 1])
-            v = v.reshape(-1, nb * 64) * out_scale
+            v = v.reshape(-1, nb * 16) * out_scale
         else:
             if bias is not None:
                 acc = acc + bias

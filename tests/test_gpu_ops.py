@@ -276,3 +276,53 @@ def test_bad_arguments_raise(hip):
         hip.gemm(a[:, :60], w[:, :60].contiguous())        # K not a multiple of 8
     with pytest.raises((TooncrafterHipError, ValueError)):
         hip.groupnorm(rnd(10, 48), torch.ones(48, device=DEV), torch.zeros(48, device=DEV), samples=1, rows=10, eps=1e-5)
+
+
+# --------------------------------------------------------------------------- wide-tile GEMM (gemm_wide.hip)
+@pytest.mark.parametrize("m,n,k,kw", [
+    (65536, 320, 320, dict(res=True)),                 # BN=320, one N tile, 256 blocks
+    (16384, 960, 320, dict()),                         # BN=320, three N tiles
+    (16500, 960, 328, dict(res=True, rb=True)),        # ragged M and K tails
+    (51200, 256, 512, dict(res=True, f32=True)),       # BN=256
+    (50000, 128, 192, dict(act=ACT_SILU)),             # BN=128
+    (24576, 640, 2560, dict(res=True)),                # long K
+    (12288, 1536, 512, dict()),                        # N not a multiple of 320 -> BN=256, N tail (1536 = 6*256)
+    (49152, 416, 64, dict()),                          # N tail inside the last BN=256 tile
+])
+def test_gemm_wide_linear(hip, emu, m, n, k, kw):
+    a, w = rnd(m, k, seed=60), rnd(n, k, seed=61, scale=k ** -0.5)
+    bias = rnd(n, seed=62, dtype=torch.float32)
+    res = rnd(m, n, seed=63) if kw.get("res") else None
+    rb = rnd((m + 4095) // 4096, n, seed=64, dtype=torch.float32) if kw.get("rb") else None
+    args = dict(act=kw.get("act", ACT_NONE), residual=res, row_bias=rb, row_div=4096 if rb is not None else 0,
+                out_f32=kw.get("f32", False), alpha=0.9, out_scale=1.1)
+    check(hip.gemm(a, w, bias, **args), emu.gemm(a, w, bias, **args), f"wide gemm {m}x{n}x{k} {kw}",
+          f32=kw.get("f32", False))
+
+
+def test_gemm_wide_geglu(hip):
+    from tooncrafter_amd.lvdm.common import pack_geglu
+    for m, c in ((16384, 320), (6144, 640)):
+        x = rnd(m, c, seed=65)
+        w = rnd(8 * c, c, seed=66, scale=c ** -0.5, dtype=torch.float32)
+        b = rnd(8 * c, seed=67, dtype=torch.float32)
+        wp, bp = pack_geglu(w, b)
+        out = hip.gemm(x, wp, bp, act=ACT_GEGLU)
+        full = x.float() @ w.to(BF16).float().t() + b
+        v, gate = full.chunk(2, dim=-1)
+        check(out, (v * torch.nn.functional.gelu(gate)).to(BF16), f"wide GEGLU m{m} c{c}")
+
+
+@pytest.mark.parametrize("frames,h,w,cin,cout,t3", [
+    (32, 40, 64, 320, 320, False), (32, 40, 64, 64, 320, False), (16, 80, 128, 128, 256, False),
+    (32, 40, 64, 320, 320, True), (16, 64, 64, 128, 128, True)])
+def test_gemm_wide_conv(hip, emu, frames, h, w, cin, cout, t3):
+    x = rnd(frames * h * w, cin, seed=68)
+    taps = 3 if t3 else 9
+    wt = rnd(cout, taps * cin, seed=69, scale=(taps * cin) ** -0.5)
+    bias = rnd(cout, seed=70, dtype=torch.float32)
+    res = rnd(frames * h * w, cout, seed=71)
+    geom = dict(kind="t3", frames=frames, t_len=16, cin=cin, h_out=h, w_out=w) if t3 else \
+        dict(kind="3x3", frames=frames, cin=cin, h_in=h, w_in=w, h_out=h, w_out=w, stride=1, upsample=False)
+    check(hip.gemm(x, wt, bias, conv=geom, residual=res), emu.gemm(x, wt, bias, conv=geom, residual=res),
+          f"wide conv t3={t3} f{frames} {h}x{w} {cin}->{cout}")

@@ -19,29 +19,17 @@
 // activation / residual / GEGLU math and the global stores run on 16-byte row vectors, with
 // a fully unrolled, unconditional fast path for whole vectors.  Blocks are numbered so that
 // all N-tiles of one M-tile land on the same XCD (its L2 then serves the A re-reads).
-#include "common.h"
+#include "gemm_common.h"
+
+#include <stdlib.h>
 
 namespace {
 
-constexpr int BK = 64;
+constexpr int BK = TC_BK;
 // Tile = (64*TM) x (64*TN): 4 waves as 2x2, each wave (32*TM) x (32*TN) = TM x TN MFMA sub-tiles.
-// 128x128 (TM=TN=2) is the workhorse; 64x64 (TM=TN=1) quadruples the block count for the
-// low-resolution layers whose 128-tiles would not fill the 256 CUs.
-
-__device__ __forceinline__ int lds_off(int row, int chunk) {
-  return row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4);
-}
-
-__device__ __forceinline__ u32x4 mask4(const u32x4& v, bool keep) {
-  const uint32_t m = keep ? 0xffffffffu : 0u;
-  return u32x4{v[0] & m, v[1] & m, v[2] & m, v[3] & m};
-}
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-  if (act == TC_ACT_SILU) return silu_f(v);
-  if (act == TC_ACT_GELU) return gelu_erf_f(v);
-  return v;
-}
+// 128x128 (TM=TN=2) is the general kernel; 64x64 (TM=TN=1) quadruples the block count for the
+// low-resolution layers whose 128-tiles would not fill the 256 CUs; the big-M layers go to the
+// 256-row kernel of gemm_wide.hip.
 
 // ---- epilogue over the fp32 tile staged in LDS ----------------------------------------
 // Fast path: every 8-column vector of the tile is fully inside N and 16-byte addressable.
@@ -59,13 +47,16 @@ __device__ __forceinline__ void epilogue_fast(const TcGemmParams& p, const float
   float bv[8], bg[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { bv[e] = 0.f; bg[e] = 0.f; }
+  // GEGLU weights are packed per 32 rows as [16 values | 16 gates]: output column j of this tile
+  // lives at packed column 32*(j/16) + j%16, its gate 16 columns further
+  const int pc = GEGLU ? 32 * ((g * 8) / 16) + (g * 8) % 16 : g * 8;
   if (p.bias) {
-    const float* bp = p.bias + (GEGLU ? tile_n * BN + g * 8 : n0);
+    const float* bp = p.bias + (GEGLU ? tile_n * BN + pc : n0);
     const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
     if (GEGLU) {
-      const f32x4 g0 = *reinterpret_cast<const f32x4*>(bp + BN / 2), g1 = *reinterpret_cast<const f32x4*>(bp + BN / 2 + 4);
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(bp + 16), g1 = *reinterpret_cast<const f32x4*>(bp + 20);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { bg[e] = g0[e]; bg[4 + e] = g1[e]; }
     }
@@ -95,14 +86,14 @@ __device__ __forceinline__ void epilogue_fast(const TcGemmParams& p, const float
     const int m = tile_m * BM + row;
     float x[8];
     {
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(cs + row * BN + g * 8);
-      const f32x4 hi = *reinterpret_cast<const f32x4*>(cs + row * BN + g * 8 + 4);
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(cs + row * BN + pc);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(cs + row * BN + pc + 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { x[e] = lo[e]; x[4 + e] = hi[e]; }
     }
     if (GEGLU) {
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(cs + row * BN + BN / 2 + g * 8);
-      const f32x4 hi = *reinterpret_cast<const f32x4*>(cs + row * BN + BN / 2 + g * 8 + 4);
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(cs + row * BN + pc + 16);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(cs + row * BN + pc + 20);
       float gt[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) { gt[e] = lo[e]; gt[4 + e] = hi[e]; }
@@ -375,16 +366,26 @@ extern "C" int tc_gemm_bf16(const TcGemmParams* pp, void* stream) {
   } else {
     return TC_EINVAL;
   }
-  // tile choice: 128x128 unless that leaves most of the 256 CUs idle (low-resolution layers)
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // TC_GEMM_TILE = wide | big | small forces one tile family (tuning / A-B runs); default: heuristic
+  static const int force = [] {
+    const char* e = getenv("TC_GEMM_TILE");
+    if (!e) return 0;
+    return e[0] == 'w' ? 1 : e[0] == 'b' ? 2 : e[0] == 's' ? 3 : 0;
+  }();
+  if (force <= 1 && tc_gemm_wide_try(p, batch, s, force == 1)) {       // big-M layers: 256-row tiles
+    TC_LAUNCH_CHECK();
+    return TC_OK;
+  }
+  // otherwise 128x128, or 64x64 when that would leave most of the 256 CUs idle (low-resolution layers)
   const int64_t big_tiles = (int64_t)((p.n + 127) / 128) * ((p.m + 127) / 128) * batch;
-  const bool small = !geglu && big_tiles < 384;
+  const bool small = force == 3 ? !geglu : force == 2 ? false : (!geglu && big_tiles < 384);
   const int bm = small ? 64 : 128, bn = small ? 64 : 128;
   const int tiles_n = (p.n + bn - 1) / bn;
   const int tiles_m = (p.m + bm - 1) / bm;
   const int64_t nblk = (int64_t)tiles_n * 8 * ((tiles_m + 7) / 8);
   if (nblk > 0x7fffffffLL || batch > 65535) return TC_ESHAPE;
   dim3 grid((unsigned)nblk, 1, (unsigned)batch), block(256);
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define TC_LAUNCH_GEMM(G)                                                              \
   do {                                                                                 \
     if (small) hipLaunchKernelGGL((gemm_kernel<G, 1, 1>), grid, block, 0, s, p);       \

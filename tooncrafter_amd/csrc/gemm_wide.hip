@@ -1,0 +1,291 @@
+// Wide-tile bf16 MFMA GEMM for the big-M layers, gfx950.
+//
+// Same contract as gemm.hip (implicit-GEMM gather, fused epilogue) with a 256-row block tile:
+//   BM = 256, BN = 32*TNW*2 in {128, 256, 320}; 8 waves as 4(M) x 2(N), each wave owns a
+//   64 x (32*TNW) patch = 2 x TNW v_mfma_f32_32x32x16_bf16 sub-tiles.
+// Why: the 128x128 kernel moves 32 KiB into and 64 KiB out of LDS per K-step for 16 MFMAs per
+// wave -- with two such blocks per CU the LDS pipe, not the MFMA pipe, sets the pace.  A 256x320
+// tile writes 2.2x fewer LDS bytes per FLOP and reads 0.7 fragments per MFMA instead of 1.0, and
+// BN = 320 divides every UNet width (320*k) exactly, so the N=320/960 layers of the highest
+// resolution stop wasting 17 % of their MFMAs on padding columns.
+// Pipeline: register-staged double-buffered LDS (2 x 72 KiB at BN=320), loads of K-step k+1 in
+// flight under the 40 MFMAs per wave of K-step k, one barrier per K-step.  Epilogue: each wave
+// transposes its accumulators through a private 10 KiB LDS slab, 16 rows at a time, and finishes
+// on 16-byte row vectors (bias / row-bias / activation / GEGLU / residual / store).
+#include "gemm_common.h"
+
+#include <stdlib.h>
+
+#include <type_traits>
+
+namespace {
+
+constexpr int WBM = 256;
+constexpr int WTHREADS = 512;
+
+template <int GATHER, int TNW>
+__global__ __launch_bounds__(WTHREADS, 2) void gemm_wide_kernel(const TcGemmParams p) {
+  constexpr int BN = 64 * TNW;
+  constexpr int WN = 32 * TNW;                         // columns per wave
+  constexpr int STAGE_BYTES = (WBM + BN) * TC_BK * 2;  // 72 KiB at BN = 320
+  constexpr int RA = WBM / 64, RB = BN / 64;           // loader rows per thread (64 rows per pass)
+  constexpr int SLAB_FLOATS = 16 * WN;                 // per-wave epilogue slab: 16 rows x WN cols
+  static_assert(8 * SLAB_FLOATS * 4 <= 2 * STAGE_BYTES, "epilogue slabs must fit in the pipeline buffers");
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int tiles_n = (p.n + BN - 1) / BN;
+  const int tiles_m = (p.m + WBM - 1) / WBM;
+  const int xcd = blockIdx.x & 7;
+  const int slot = blockIdx.x >> 3;
+  const int tile_m = (slot / tiles_n) * 8 + xcd;
+  const int tile_n = slot % tiles_n;
+  if (tile_m >= tiles_m) return;
+
+  const int64_t bz = blockIdx.z;
+  const bf16_t* __restrict__ a_base = reinterpret_cast<const bf16_t*>(p.a) + bz * p.stride_a;
+  const bf16_t* __restrict__ w_base = reinterpret_cast<const bf16_t*>(p.w) + bz * p.stride_w;
+
+  const int lrow = tid >> 3;     // 0..63
+  const int chunk = tid & 7;
+  AGather<GATHER, RA> ag;
+  ag.init(p, tile_m * WBM, lrow, 64);
+  bool b_ok[RB];
+  const bf16_t* b_ptr[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) {
+    const int n = tile_n * BN + lrow + 64 * i;
+    b_ok[i] = n < p.n;
+    b_ptr[i] = w_base + (int64_t)(b_ok[i] ? n : p.n - 1) * p.ldw;
+  }
+
+  u32x4 ra[RA], rb[RB];
+  auto load_tile = [&](int kb) {
+    const int k0 = kb * TC_BK;
+    const bool k_ok = k0 + chunk * 8 < p.k;
+    const int kc = k_ok ? k0 + chunk * 8 : 0;
+#pragma unroll
+    for (int i = 0; i < RB; ++i) rb[i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + kc);
+    ag.load(p, a_base, k0, chunk, ra);
+#pragma unroll
+    for (int i = 0; i < RB; ++i) rb[i] = mask4(rb[i], b_ok[i] && k_ok);
+  };
+  auto store_tile = [&](int stage) {
+    char* sa = smem + stage * STAGE_BYTES;
+    char* sb = sa + WBM * TC_BK * 2;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) *reinterpret_cast<u32x4*>(sa + lds_off(lrow + 64 * i, chunk)) = ra[i];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) *reinterpret_cast<u32x4*>(sb + lds_off(lrow + 64 * i, chunk)) = rb[i];
+  };
+
+  f32x16 acc[2][TNW];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TNW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frow = lane & 31;
+  const int fhalf = lane >> 5;
+
+  auto compute = [&](int stage) {
+    const char* sa = smem + stage * STAGE_BYTES;
+    const char* sb = sa + WBM * TC_BK * 2;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int c = kk * 2 + fhalf;
+      bf16x8 af[2], bf[TNW];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(wm * 64 + i * 32 + frow, c));
+#pragma unroll
+      for (int j = 0; j < TNW; ++j)
+        bf[j] = *reinterpret_cast<const bf16x8*>(sb + lds_off(wn * WN + j * 32 + frow, c));
+#pragma unroll
+      for (int j = 0; j < TNW; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int nk = (p.k + TC_BK - 1) / TC_BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kb = 0; kb < nk; ++kb) {
+    const bool more = kb + 1 < nk;
+    if (more) load_tile(kb + 1);
+    compute(kb & 1);
+    if (more) store_tile((kb + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: per wave, 4 passes of 16 rows through a private fp32 slab
+  const bool geglu = p.act == TC_ACT_GEGLU;
+  const int n_out = geglu ? p.n / 2 : p.n;
+  float* slab = reinterpret_cast<float*>(smem) + wave * SLAB_FLOATS;
+  const bf16_t* res_base = p.residual ? reinterpret_cast<const bf16_t*>(p.residual) + bz * p.stride_c : nullptr;
+  char* c_base = reinterpret_cast<char*>(p.c) + bz * p.stride_c * (p.out_f32 ? 4 : 2);
+  const int col_w0 = tile_n * BN + wn * WN;          // first packed column of this wave
+
+  // one pass = 16 rows; called with compile-time (i, half) so the accumulator indices stay static
+  // (a runtime index would send the whole accumulator file to scratch)
+  auto epi_pass = [&](auto I_, auto H_) {
+    constexpr int i = decltype(I_)::value, half = decltype(H_)::value;
+    // accumulator registers r = 8*half .. 8*half+7 hold local rows (r&3) + 4*fhalf + 8*((r>>2)&1)
+#pragma unroll
+    for (int j = 0; j < TNW; ++j)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int r = 8 * half + q;
+        const int lr = (r & 3) + 4 * fhalf + 8 * ((r >> 2) & 1);
+        slab[lr * WN + j * 32 + frow] = acc[i][j][r];
+      }
+    // same wave reads back: LDS operations of one wave complete in order
+    const int row_base = tile_m * WBM + wm * 64 + i * 32 + half * 16;
+    if (!geglu) {
+      constexpr int VPR = WN / 8;                    // 8-column vectors per slab row
+      constexpr int NV = 16 * VPR / 64;              // vectors per lane (exact for WN in {64,128,160})
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        const int v = lane + 64 * q;
+        const int lr = v / VPR, vc = v - lr * VPR;
+        const int m = row_base + lr;
+        const int n0 = col_w0 + vc * 8;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(slab + lr * WN + vc * 8);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(slab + lr * WN + vc * 8 + 4);
+        if (m < p.m && n0 < p.n) {
+          float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          if (p.bias) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n0);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n0 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
+          }
+          if (p.row_bias) {
+            const float* rp = p.row_bias + (int64_t)(m / p.row_div) * p.ldrb + n0;
+            const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp);
+            const f32x4 r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { bv[e] += r0[e]; bv[4 + e] += r1[e]; }
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = apply_act(x[e] * p.alpha + bv[e], p.act) * p.out_scale;
+          if (res_base) {
+            float rf[8];
+            unpack8(*reinterpret_cast<const u32x4*>(res_base + (int64_t)m * p.ldr + n0), rf);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] += rf[e];
+          }
+          if (p.out_f32) {
+            float* op = reinterpret_cast<float*>(c_base) + (int64_t)m * p.ldc + n0;
+            *reinterpret_cast<f32x4*>(op) = f32x4{x[0], x[1], x[2], x[3]};
+            *reinterpret_cast<f32x4*>(op + 4) = f32x4{x[4], x[5], x[6], x[7]};
+          } else {
+            *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(c_base) + (int64_t)m * p.ldc + n0) = pack8(x);
+          }
+        }
+      }
+    } else {
+      // packed columns: every 32 = [16 values | 16 gates]; output vector u (8 columns) of a slab row
+      // reads values at packed 32*(u/2) + 8*(u&1) and gates 16 further
+      constexpr int VPR = WN / 16;                   // output vectors per slab row
+      constexpr int TOT = 16 * VPR;
+#pragma unroll
+      for (int q = 0; q < (TOT + 63) / 64; ++q) {
+        const int v = lane + 64 * q;
+        const int lr = v / VPR, u = v - lr * VPR;
+        const int m = row_base + lr;
+        const int pc = 32 * (u >> 1) + 8 * (u & 1);            // packed column inside the wave's slab
+        const int n0 = (col_w0 >> 1) + u * 8;                  // output column
+        if (v < TOT && m < p.m && n0 < n_out) {
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(slab + lr * WN + pc);
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(slab + lr * WN + pc + 4);
+          const f32x4 glo = *reinterpret_cast<const f32x4*>(slab + lr * WN + pc + 16);
+          const f32x4 ghi = *reinterpret_cast<const f32x4*>(slab + lr * WN + pc + 20);
+          float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          float gt[8] = {glo[0], glo[1], glo[2], glo[3], ghi[0], ghi[1], ghi[2], ghi[3]};
+          float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, bg[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          if (p.bias) {
+            const float* bp = p.bias + col_w0 + pc;
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(bp + 16), g1 = *reinterpret_cast<const f32x4*>(bp + 20);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; bg[e] = g0[e]; bg[4 + e] = g1[e]; }
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            x[e] = (x[e] * p.alpha + bv[e]) * gelu_erf_f(gt[e] * p.alpha + bg[e]) * p.out_scale;
+          if (p.out_f32) {
+            float* op = reinterpret_cast<float*>(c_base) + (int64_t)m * p.ldc + n0;
+            *reinterpret_cast<f32x4*>(op) = f32x4{x[0], x[1], x[2], x[3]};
+            *reinterpret_cast<f32x4*>(op + 4) = f32x4{x[4], x[5], x[6], x[7]};
+          } else {
+            *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(c_base) + (int64_t)m * p.ldc + n0) = pack8(x);
+          }
+        }
+      }
+    }
+  };
+  using std::integral_constant;
+  epi_pass(integral_constant<int, 0>{}, integral_constant<int, 0>{});
+  epi_pass(integral_constant<int, 0>{}, integral_constant<int, 1>{});
+  epi_pass(integral_constant<int, 1>{}, integral_constant<int, 0>{});
+  epi_pass(integral_constant<int, 1>{}, integral_constant<int, 1>{});
+}
+
+template <int TNW>
+void launch_wide(const TcGemmParams& p, dim3 grid, hipStream_t s) {
+  dim3 block(WTHREADS);
+  switch (p.gather) {
+    case TC_GATHER_LINEAR: hipLaunchKernelGGL((gemm_wide_kernel<TC_GATHER_LINEAR, TNW>), grid, block, 0, s, p); break;
+    case TC_GATHER_CONV3x3: hipLaunchKernelGGL((gemm_wide_kernel<TC_GATHER_CONV3x3, TNW>), grid, block, 0, s, p); break;
+    default: hipLaunchKernelGGL((gemm_wide_kernel<TC_GATHER_CONVT3, TNW>), grid, block, 0, s, p); break;
+  }
+}
+
+int wide_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("TC_GEMM_WIDE");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
+
+}  // namespace
+
+// Decide whether the wide kernel should take this (already validated) GEMM, and launch it.
+int tc_gemm_wide_try(const TcGemmParams& p, int batch, hipStream_t s, bool force) {
+  if (!wide_enabled()) return 0;
+  const bool geglu = p.act == TC_ACT_GEGLU;
+  const int n_out = geglu ? p.n / 2 : p.n;
+  if ((n_out & 7) != 0 || (p.n & 31) != 0) return 0;       // vector epilogue only; GEGLU packs per 32
+  int tnw;
+  if (p.n % 320 == 0) tnw = 5;
+  else if (p.n >= 256) tnw = 4;
+  else if (p.n >= 128) tnw = 2;
+  else return 0;
+  const int bn = 64 * tnw;
+  const int tiles_n = (p.n + bn - 1) / bn;
+  const int tiles_m = (p.m + WBM - 1) / WBM;
+  const int64_t blocks = (int64_t)tiles_n * tiles_m * batch;
+  // measured on MI355X (profiles/r01_gemm_tile_sweep.txt): the 256-row tile wins only when there is
+  // enough K to amortise its single-block-per-CU prologue/epilogue and enough N to matter
+  if (!force && (blocks < 192 || p.n < 512 || p.k < 512)) return 0;
+  const int64_t nblk = (int64_t)tiles_n * 8 * ((tiles_m + 7) / 8);
+  if (nblk > 0x7fffffffLL) return 0;
+  dim3 grid((unsigned)nblk, 1, (unsigned)batch);
+  if (tnw == 5) launch_wide<5>(p, grid, s);
+  else if (tnw == 4) launch_wide<4>(p, grid, s);
+  else launch_wide<2>(p, grid, s);
+  return 1;
+}

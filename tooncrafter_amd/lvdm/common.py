@@ -76,16 +76,17 @@ def pack_convt3(w: torch.Tensor) -> torch.Tensor:
 
 
 def pack_geglu(w: torch.Tensor, b: torch.Tensor):
-    """GEGLU proj [2F, C] (rows [0,F) values, [F,2F) gates) -> per 128-row block
-    64 value rows followed by their 64 gate rows; bias likewise (fp32)."""
+    """GEGLU proj [2F, C] (rows [0,F) values, [F,2F) gates) -> every 32 packed rows hold 16 value
+    rows followed by their 16 gate rows (independent of the GEMM tile shape: the gate of packed
+    column c sits at c + 16); bias likewise (fp32)."""
     w = w.detach()
     b = b.detach()
     f2, c = w.shape
     f = f2 // 2
-    assert f % 64 == 0
-    wv, wg = w[:f].reshape(f // 64, 64, c), w[f:].reshape(f // 64, 64, c)
+    assert f % 16 == 0
+    wv, wg = w[:f].reshape(f // 16, 16, c), w[f:].reshape(f // 16, 16, c)
     wp = torch.cat([wv, wg], dim=1).reshape(f2, c)
-    bv, bg = b[:f].reshape(f // 64, 64), b[f:].reshape(f // 64, 64)
+    bv, bg = b[:f].reshape(f // 16, 16), b[f:].reshape(f // 16, 16)
     bp = torch.cat([bv, bg], dim=1).reshape(f2)
     kp = ceil_to(c, 8)
     out = torch.zeros((f2, kp), dtype=BF16, device=w.device)
