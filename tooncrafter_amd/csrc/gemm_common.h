@@ -49,10 +49,13 @@ struct AGather {
     }
   }
 
-  // loads this thread's 16-byte chunk of each of its rows for K-block starting at k0 (branch-free:
-  // out-of-range rows/taps read a clamped in-bounds address and are zeroed afterwards)
-  __device__ __forceinline__ void load(const TcGemmParams& p, const bf16_t* __restrict__ a_base, int k0, int chunk,
-                                       u32x4 (&ra)[R]) const {
+  // Issues the loads of this thread's 16-byte chunk of each of its rows for the K-block starting at
+  // k0.  Branch-free: out-of-range rows/taps read a clamped in-bounds address; bit i of the returned
+  // mask says whether row i is real.  The caller zeroes invalid rows when it WRITES them to LDS
+  // (apply_mask) -- touching the loaded registers here would make the compiler wait for the loads
+  // before the MFMAs of the current tile instead of overlapping them.
+  __device__ __forceinline__ unsigned load(const TcGemmParams& p, const bf16_t* __restrict__ a_base, int k0, int chunk,
+                                           u32x4 (&ra)[R]) const {
     const bool k_ok = k0 + chunk * 8 < p.k;
     const int kc = k_ok ? k0 + chunk * 8 : 0;
     bool v[R];
@@ -92,9 +95,17 @@ struct AGather {
         ra[i] = *reinterpret_cast<const u32x4*>(a_base + src * p.lda + c0);
       }
     }
+    unsigned mask = 0;
 #pragma unroll
-    for (int i = 0; i < R; ++i) ra[i] = mask4(ra[i], v[i] && k_ok);
+    for (int i = 0; i < R; ++i) mask |= (v[i] && k_ok) ? (1u << i) : 0u;
+    return mask;
   }
 };
+
+template <int R>
+__device__ __forceinline__ void apply_mask(u32x4 (&r)[R], unsigned mask) {
+#pragma unroll
+  for (int i = 0; i < R; ++i) r[i] = mask4(r[i], (mask >> i) & 1u);
+}
 
 int tc_gemm_wide_try(const TcGemmParams& p, int batch, hipStream_t s, bool force);   // gemm_wide.hip; 1 = launched

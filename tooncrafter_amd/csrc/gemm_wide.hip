@@ -64,19 +64,24 @@ __global__ __launch_bounds__(WTHREADS, 2) void gemm_wide_kernel(const TcGemmPara
   }
 
   u32x4 ra[RA], rb[RB];
+  unsigned amask = 0, bmask = 0;
+  unsigned b_okbits = 0;
+#pragma unroll
+  for (int i = 0; i < RB; ++i) b_okbits |= b_ok[i] ? (1u << i) : 0u;
   auto load_tile = [&](int kb) {
     const int k0 = kb * TC_BK;
     const bool k_ok = k0 + chunk * 8 < p.k;
     const int kc = k_ok ? k0 + chunk * 8 : 0;
 #pragma unroll
     for (int i = 0; i < RB; ++i) rb[i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + kc);
-    ag.load(p, a_base, k0, chunk, ra);
-#pragma unroll
-    for (int i = 0; i < RB; ++i) rb[i] = mask4(rb[i], b_ok[i] && k_ok);
+    amask = ag.load(p, a_base, k0, chunk, ra);
+    bmask = k_ok ? b_okbits : 0u;
   };
   auto store_tile = [&](int stage) {
     char* sa = smem + stage * STAGE_BYTES;
     char* sb = sa + WBM * TC_BK * 2;
+    apply_mask(ra, amask);
+    apply_mask(rb, bmask);
 #pragma unroll
     for (int i = 0; i < RA; ++i) *reinterpret_cast<u32x4*>(sa + lds_off(lrow + 64 * i, chunk)) = ra[i];
 #pragma unroll
