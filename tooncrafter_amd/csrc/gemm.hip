@@ -174,87 +174,38 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams p) {
   // ---- loader geometry: thread -> (row lrow + 32 i, 16-byte chunk) of both tiles
   const int lrow = tid >> 3;
   const int chunk = tid & 7;
-  const int hw = p.h_out * p.w_out;
-  bool a_ok[RA], b_ok[RB];
-  int a_m[RA];                      // clamped output row
-  int a_f[RA], a_y[RA], a_x[RA];    // frame / y / x (CONV3x3) or t-in-clip in a_y (CONVT3)
+  AGather<GATHER, RA> ag;
+  ag.init(p, tile_m * BM, lrow, 32);
   const bf16_t* b_ptr[RB];
-#pragma unroll
-  for (int i = 0; i < RA; ++i) {
-    const int m = tile_m * BM + lrow + 32 * i;
-    a_ok[i] = m < p.m;
-    const int mc = a_ok[i] ? m : p.m - 1;
-    a_m[i] = mc;
-    a_f[i] = a_y[i] = a_x[i] = 0;
-    if (GATHER == TC_GATHER_CONV3x3) {
-      const int q = mc / p.w_out;
-      a_x[i] = mc - q * p.w_out;
-      a_f[i] = q / p.h_out;
-      a_y[i] = q - a_f[i] * p.h_out;
-    } else if (GATHER == TC_GATHER_CONVT3) {
-      a_y[i] = (mc / hw) % p.t_len;
-    }
-  }
+  unsigned b_okbits = 0;
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
     const int n = tile_n * BN + lrow + 32 * i;
-    b_ok[i] = n < p.n;
-    b_ptr[i] = w_base + (int64_t)(b_ok[i] ? n : p.n - 1) * p.ldw;
+    const bool ok = n < p.n;
+    b_okbits |= ok ? (1u << i) : 0u;
+    b_ptr[i] = w_base + (int64_t)(ok ? n : p.n - 1) * p.ldw;
   }
-  const int hv = p.upsample ? p.h_in * 2 : p.h_in;
-  const int wv = p.upsample ? p.w_in * 2 : p.w_in;
 
   u32x4 ra[RA], rb[RB];
+  unsigned amask = 0, bmask = 0;
 
+  // issue the global loads of K-step kb (nothing here touches the loaded registers, so the MFMAs of
+  // the current tile run while these are in flight; invalid rows are zeroed when written to LDS)
   auto load_tile = [&](int kb) {
     const int k0 = kb * BK;
     const bool k_ok = k0 + chunk * 8 < p.k;
     const int kc = k_ok ? k0 + chunk * 8 : 0;
 #pragma unroll
     for (int i = 0; i < RB; ++i) rb[i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + kc);
-    bool ok[RA];
-    if (GATHER == TC_GATHER_LINEAR) {
-#pragma unroll
-      for (int i = 0; i < RA; ++i) {
-        ra[i] = *reinterpret_cast<const u32x4*>(a_base + (int64_t)a_m[i] * p.lda + kc);
-        ok[i] = a_ok[i];
-      }
-    } else if (GATHER == TC_GATHER_CONV3x3) {
-      const int tap = k0 / p.cin;
-      const int c0 = k0 - tap * p.cin + chunk * 8;
-      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-#pragma unroll
-      for (int i = 0; i < RA; ++i) {
-        int iy = a_y[i] * p.stride + dy;
-        int ix = a_x[i] * p.stride + dx;
-        ok[i] = a_ok[i] && iy >= 0 && iy < hv && ix >= 0 && ix < wv;
-        iy = ok[i] ? iy : 0;
-        ix = ok[i] ? ix : 0;
-        if (p.upsample) { iy >>= 1; ix >>= 1; }
-        const int64_t src = ((int64_t)a_f[i] * p.h_in + iy) * p.w_in + ix;
-        ra[i] = *reinterpret_cast<const u32x4*>(a_base + src * p.lda + c0);
-      }
-    } else {  // CONVT3
-      const int tap = k0 / p.cin;
-      const int c0 = k0 - tap * p.cin + chunk * 8;
-      const int dt = tap - 1;
-#pragma unroll
-      for (int i = 0; i < RA; ++i) {
-        const int tt = a_y[i] + dt;
-        ok[i] = a_ok[i] && tt >= 0 && tt < p.t_len;
-        const int64_t src = (int64_t)a_m[i] + (ok[i] ? (int64_t)dt * hw : 0);
-        ra[i] = *reinterpret_cast<const u32x4*>(a_base + src * p.lda + c0);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < RA; ++i) ra[i] = mask4(ra[i], ok[i] && k_ok);
-#pragma unroll
-    for (int i = 0; i < RB; ++i) rb[i] = mask4(rb[i], b_ok[i] && k_ok);
+    amask = ag.load(p, a_base, k0, chunk, ra);
+    bmask = k_ok ? b_okbits : 0u;
   };
 
   auto store_tile = [&](int stage) {
     char* sa = smem + stage * STAGE_BYTES;
     char* sb = sa + BM * BK * 2;
+    apply_mask(ra, amask);
+    apply_mask(rb, bmask);
 #pragma unroll
     for (int i = 0; i < RA; ++i) *reinterpret_cast<u32x4*>(sa + lds_off(lrow + 32 * i, chunk)) = ra[i];
 #pragma unroll
