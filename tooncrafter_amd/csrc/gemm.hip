@@ -23,6 +23,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace {
 
 constexpr int BK = TC_BK;
@@ -33,7 +35,10 @@ constexpr int BK = TC_BK;
 
 // ---- epilogue over the fp32 tile staged in LDS ----------------------------------------
 // Fast path: every 8-column vector of the tile is fully inside N and 16-byte addressable.
-template <bool GEGLU, int BM, int BN>
+// PLAIN = the common "acc + bias (+ residual)" case (alpha = out_scale = 1, no activation, no row bias):
+// with K as short as 320 the epilogue is a third of a block's instructions, so it gets its own
+// straight-line instance without the per-element multiplies and activation selects.
+template <bool GEGLU, int BM, int BN, bool PLAIN>
 __device__ __forceinline__ void epilogue_fast(const TcGemmParams& p, const float* cs, int tid, int tile_m, int tile_n,
                                               int64_t bz) {
   constexpr int GROUPS = GEGLU ? BN / 16 : BN / 8;   // 8-column groups per output row of this tile
@@ -74,7 +79,7 @@ __device__ __forceinline__ void epilogue_fast(const TcGemmParams& p, const float
     rb0[it] = f32x4{0.f, 0.f, 0.f, 0.f};
     rb1[it] = rb0[it];
     if (res_base) rres[it] = *reinterpret_cast<const u32x4*>(res_base + (int64_t)mc * p.ldr + n0);
-    if (!GEGLU && p.row_bias) {
+    if (!GEGLU && !PLAIN && p.row_bias) {
       const float* rp = p.row_bias + (int64_t)(mc / p.row_div) * p.ldrb + n0;
       rb0[it] = *reinterpret_cast<const f32x4*>(rp);
       rb1[it] = *reinterpret_cast<const f32x4*>(rp + 4);
@@ -103,8 +108,12 @@ __device__ __forceinline__ void epilogue_fast(const TcGemmParams& p, const float
     } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float rbv = e < 4 ? rb0[it][e] : rb1[it][e - 4];
-        x[e] = apply_act(x[e] * p.alpha + bv[e] + rbv, p.act) * p.out_scale;
+        if (PLAIN) {
+          x[e] += bv[e];
+        } else {
+          const float rbv = e < 4 ? rb0[it][e] : rb1[it][e - 4];
+          x[e] = apply_act(x[e] * p.alpha + bv[e] + rbv, p.act) * p.out_scale;
+        }
       }
     }
     if (res_base) {
@@ -168,44 +177,40 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams p) {
   if (tile_m >= tiles_m) return;
 
   const int64_t bz = blockIdx.z;
-  const bf16_t* __restrict__ a_base = reinterpret_cast<const bf16_t*>(p.a) + bz * p.stride_a;
-  const bf16_t* __restrict__ w_base = reinterpret_cast<const bf16_t*>(p.w) + bz * p.stride_w;
+  const tc_rsrc_t a_rsrc = make_rsrc(reinterpret_cast<const bf16_t*>(p.a) + bz * p.stride_a);
+  const tc_rsrc_t w_rsrc = make_rsrc(reinterpret_cast<const bf16_t*>(p.w) + bz * p.stride_w);
 
   // ---- loader geometry: thread -> (row lrow + 32 i, 16-byte chunk) of both tiles
   const int lrow = tid >> 3;
   const int chunk = tid & 7;
   AGather<GATHER, RA> ag;
-  ag.init(p, tile_m * BM, lrow, 32);
-  const bf16_t* b_ptr[RB];
-  unsigned b_okbits = 0;
+  ag.init(p, tile_m * BM, lrow, 32, chunk);
+  uint32_t b_voff[RB];
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
     const int n = tile_n * BN + lrow + 32 * i;
-    const bool ok = n < p.n;
-    b_okbits |= ok ? (1u << i) : 0u;
-    b_ptr[i] = w_base + (int64_t)(ok ? n : p.n - 1) * p.ldw;
+    b_voff[i] = n < p.n ? (uint32_t)((int64_t)n * p.ldw * 2 + chunk * 16) : TC_OOB;
   }
+  const bool k_ragged = (p.k & (BK - 1)) != 0;      // linear layers only (conv K is a multiple of 64)
 
   u32x4 ra[RA], rb[RB];
-  unsigned amask = 0, bmask = 0;
 
-  // issue the global loads of K-step kb (nothing here touches the loaded registers, so the MFMAs of
-  // the current tile run while these are in flight; invalid rows are zeroed when written to LDS)
+  // issue the buffer loads of K-step kb: scalar K offset, per-lane row offsets fixed for the whole
+  // block, out-of-range rows return zeros -- nothing here costs VALU in the steady state
   auto load_tile = [&](int kb) {
     const int k0 = kb * BK;
-    const bool k_ok = k0 + chunk * 8 < p.k;
-    const int kc = k_ok ? k0 + chunk * 8 : 0;
+    uint32_t a_voff[RA], a_soff;
+    ag.offsets(p, k0, chunk, a_voff, a_soff);
+    const bool dead = k_ragged && (k0 + chunk * 8 >= p.k);   // this thread's chunk lies beyond K
 #pragma unroll
-    for (int i = 0; i < RB; ++i) rb[i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + kc);
-    amask = ag.load(p, a_base, k0, chunk, ra);
-    bmask = k_ok ? b_okbits : 0u;
+    for (int i = 0; i < RB; ++i) rb[i] = buf_load16(w_rsrc, dead ? TC_OOB : b_voff[i], (uint32_t)k0 * 2u);
+#pragma unroll
+    for (int i = 0; i < RA; ++i) ra[i] = buf_load16(a_rsrc, dead ? TC_OOB : a_voff[i], a_soff);
   };
 
   auto store_tile = [&](int stage) {
     char* sa = smem + stage * STAGE_BYTES;
     char* sb = sa + BM * BK * 2;
-    apply_mask(ra, amask);
-    apply_mask(rb, bmask);
 #pragma unroll
     for (int i = 0; i < RA; ++i) *reinterpret_cast<u32x4*>(sa + lds_off(lrow + 32 * i, chunk)) = ra[i];
 #pragma unroll
@@ -223,25 +228,43 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams p) {
   const int frow = lane & 31;
   const int fhalf = lane >> 5;
 
+  // MFMA fragments are double-buffered in registers: the ds_reads of K-slice kk+1 are issued BEFORE the
+  // MFMAs of slice kk, so LDS latency hides under the matrix pipe.
   auto compute = [&](int stage) {
     const char* sa = smem + stage * STAGE_BYTES;
     const char* sb = sa + BM * BK * 2;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    bf16x8 af[2][TM], bf[2][TN];
+    auto frags = [&](int kk, bf16x8 (&a)[TM], bf16x8 (&b)[TN]) {
       const int c = kk * 2 + fhalf;
-      bf16x8 af[TM], bf[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        af[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(wm * 32 * TM + i * 32 + frow, c));
+        a[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(wm * 32 * TM + i * 32 + frow, c));
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        bf[j] = *reinterpret_cast<const bf16x8*>(sb + lds_off(wn * 32 * TN + j * 32 + frow, c));
+        b[j] = *reinterpret_cast<const bf16x8*>(sb + lds_off(wn * 32 * TN + j * 32 + frow, c));
+    };
+    auto mfmas = [&](bf16x8 (&a)[TM], bf16x8 (&b)[TN]) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-    }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    };
+    // sched_barrier(0) pins this order (hipcc would otherwise merge the two fragment sets back into one)
+    frags(0, af[0], bf[0]);
+    frags(1, af[1], bf[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(af[0], bf[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    frags(2, af[0], bf[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(af[1], bf[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    frags(3, af[1], bf[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(af[0], bf[0]);
+    mfmas(af[1], bf[1]);
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   const int nk = (p.k + BK - 1) / BK;
@@ -272,8 +295,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams p) {
 
   const int n_out = p.act == TC_ACT_GEGLU ? p.n / 2 : p.n;
   if ((n_out & 7) != 0) epilogue_tail<BM, BN>(p, cs, tid, tile_m, tile_n, bz);
-  else if (TN == 2 && p.act == TC_ACT_GEGLU) epilogue_fast<true, BM, BN>(p, cs, tid, tile_m, tile_n, bz);
-  else epilogue_fast<false, BM, BN>(p, cs, tid, tile_m, tile_n, bz);
+  else if (TN == 2 && p.act == TC_ACT_GEGLU) epilogue_fast<true, BM, BN, false>(p, cs, tid, tile_m, tile_n, bz);
+  else if (p.alpha == 1.f && p.out_scale == 1.f && p.act == TC_ACT_NONE && !p.row_bias)
+    epilogue_fast<false, BM, BN, true>(p, cs, tid, tile_m, tile_n, bz);
+  else epilogue_fast<false, BM, BN, false>(p, cs, tid, tile_m, tile_n, bz);
 }
 
 }  // namespace
@@ -317,6 +342,7 @@ extern "C" int tc_gemm_bf16(const TcGemmParams* pp, void* stream) {
   } else {
     return TC_EINVAL;
   }
+  if (!tc_gemm_offsets_fit(p)) return TC_ESHAPE;          // buffer-load offsets are 31-bit
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // TC_GEMM_TILE = wide | big | small forces one tile family (tuning / A-B runs); default: heuristic
   static const int force = [] {

@@ -11,101 +11,124 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * (TC_BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-__device__ __forceinline__ u32x4 mask4(const u32x4& v, bool keep) {
-  const uint32_t m = keep ? 0xffffffffu : 0u;
-  return u32x4{v[0] & m, v[1] & m, v[2] & m, v[3] & m};
-}
-
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == TC_ACT_SILU) return silu_f(v);
   if (act == TC_ACT_GELU) return gelu_erf_f(v);
   return v;
 }
 
-// Per-thread gather state for `R` rows of the A tile (row = lrow + 64*i or lrow + 32*i).
+// ---------------------------------------------------------------------------------------------
+// Tile loads go through buffer_load_dwordx4 (raw buffer, 128-bit SRD in SGPRs):
+//     address = base(SRD) + voffset(VGPR, per lane) + soffset(SGPR, per K-step)
+// * the per-lane voffset (row * lda + chunk) is computed ONCE per block; advancing along K is a scalar
+//   add on soffset -- the first version of this kernel recomputed 64-bit row addresses per load and
+//   spent 12-15 VALU instructions per MFMA doing so (rocprofv3 SQ_INSTS_VALU / SQ_INSTS_MFMA), which,
+//   not memory latency, was what held it at ~25 % of the MFMA roof;
+// * rows that do not exist (M/N tails, convolution zero padding, K tails) get voffset = TC_OOB, which
+//   is >= num_records, so the hardware returns zeros: no masking instructions at all.
+// Valid offsets must stay below 2 GiB (checked on the host).
+constexpr uint32_t TC_OOB = 0x80000000u;
+constexpr int TC_SRD_FLAGS = 0x00020000;
+constexpr int TC_SRD_RECORDS = 0x7ffffff0;
+
+typedef __amdgpu_buffer_rsrc_t tc_rsrc_t;
+
+__device__ __forceinline__ tc_rsrc_t make_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, TC_SRD_RECORDS, TC_SRD_FLAGS);
+}
+
+__device__ __forceinline__ u32x4 buf_load16(tc_rsrc_t rsrc, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+}
+
+// Per-thread gather state for `R` rows of the A tile.
 template <int GATHER, int R>
 struct AGather {
+  uint32_t base[R];    // byte offset of (row, chunk) -- the centre tap for convolutions; TC_OOB if row >= M
+  uint32_t vbits[R];   // convolution: bit t set if tap t of this row is inside the image
+  int f[R], y[R], x[R];  // generic 3x3 path (stride 2 / fused upsample) only
   bool ok[R];
-  int m[R];                 // clamped output row
-  int f[R], y[R], x[R];     // frame / y / x (CONV3x3); t-in-clip in y (CONVT3)
 
-  __device__ __forceinline__ void init(const TcGemmParams& p, int tile_row0, int lrow, int row_step) {
+  __device__ __forceinline__ bool fast3x3(const TcGemmParams& p) const { return p.stride == 1 && !p.upsample; }
+
+  __device__ __forceinline__ void init(const TcGemmParams& p, int tile_row0, int lrow, int row_step, int chunk) {
     const int hw = p.h_out * p.w_out;
 #pragma unroll
     for (int i = 0; i < R; ++i) {
       const int mm = tile_row0 + lrow + row_step * i;
       ok[i] = mm < p.m;
-      const int mc = ok[i] ? mm : p.m - 1;
-      m[i] = mc;
+      const int mc = ok[i] ? mm : 0;
       f[i] = y[i] = x[i] = 0;
-      if (GATHER == TC_GATHER_CONV3x3) {
+      vbits[i] = ok[i] ? 0xffffffffu : 0u;
+      if (GATHER == TC_GATHER_LINEAR) {
+        base[i] = ok[i] ? (uint32_t)((int64_t)mc * p.lda * 2 + chunk * 16) : TC_OOB;
+      } else if (GATHER == TC_GATHER_CONV3x3) {
         const int q = mc / p.w_out;
         x[i] = mc - q * p.w_out;
         f[i] = q / p.h_out;
         y[i] = q - f[i] * p.h_out;
-      } else if (GATHER == TC_GATHER_CONVT3) {
-        y[i] = (mc / hw) % p.t_len;
+        base[i] = (uint32_t)((((int64_t)f[i] * p.h_in + y[i]) * p.w_in + x[i]) * p.lda * 2 + chunk * 16);
+        uint32_t bits = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int iy = y[i] + t / 3 - 1, ix = x[i] + t % 3 - 1;
+          if (ok[i] && iy >= 0 && iy < p.h_in && ix >= 0 && ix < p.w_in) bits |= 1u << t;
+        }
+        vbits[i] = bits;
+      } else {  // CONVT3
+        base[i] = (uint32_t)((int64_t)mc * p.lda * 2 + chunk * 16);
+        const int tt = (mc / hw) % p.t_len;
+        vbits[i] = ok[i] ? ((tt > 0 ? 1u : 0u) | 2u | (tt + 1 < p.t_len ? 4u : 0u)) : 0u;
       }
     }
   }
 
-  // Issues the loads of this thread's 16-byte chunk of each of its rows for the K-block starting at
-  // k0.  Branch-free: out-of-range rows/taps read a clamped in-bounds address; bit i of the returned
-  // mask says whether row i is real.  The caller zeroes invalid rows when it WRITES them to LDS
-  // (apply_mask) -- touching the loaded registers here would make the compiler wait for the loads
-  // before the MFMAs of the current tile instead of overlapping them.
-  __device__ __forceinline__ unsigned load(const TcGemmParams& p, const bf16_t* __restrict__ a_base, int k0, int chunk,
-                                           u32x4 (&ra)[R]) const {
-    const bool k_ok = k0 + chunk * 8 < p.k;
-    const int kc = k_ok ? k0 + chunk * 8 : 0;
-    bool v[R];
+  // voffset of every row and the scalar soffset for the K-block starting at k0
+  __device__ __forceinline__ void offsets(const TcGemmParams& p, int k0, int chunk, uint32_t (&voff)[R],
+                                          uint32_t& soff) const {
     if (GATHER == TC_GATHER_LINEAR) {
+      soff = (uint32_t)k0 * 2u;
 #pragma unroll
-      for (int i = 0; i < R; ++i) {
-        ra[i] = *reinterpret_cast<const u32x4*>(a_base + (int64_t)m[i] * p.lda + kc);
-        v[i] = ok[i];
-      }
+      for (int i = 0; i < R; ++i) voff[i] = base[i];
     } else if (GATHER == TC_GATHER_CONV3x3) {
-      const int hv = p.upsample ? p.h_in * 2 : p.h_in;
-      const int wv = p.upsample ? p.w_in * 2 : p.w_in;
       const int tap = k0 / p.cin;
-      const int c0 = k0 - tap * p.cin + chunk * 8;
+      soff = (uint32_t)(k0 - tap * p.cin) * 2u;
       const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+      if (fast3x3(p)) {
+        const uint32_t delta = (uint32_t)((dy * p.w_in + dx) * p.lda * 2);
 #pragma unroll
-      for (int i = 0; i < R; ++i) {
-        int iy = y[i] * p.stride + dy;
-        int ix = x[i] * p.stride + dx;
-        v[i] = ok[i] && iy >= 0 && iy < hv && ix >= 0 && ix < wv;
-        iy = v[i] ? iy : 0;
-        ix = v[i] ? ix : 0;
-        if (p.upsample) { iy >>= 1; ix >>= 1; }
-        const int64_t src = ((int64_t)f[i] * p.h_in + iy) * p.w_in + ix;
-        ra[i] = *reinterpret_cast<const u32x4*>(a_base + src * p.lda + c0);
+        for (int i = 0; i < R; ++i) voff[i] = ((vbits[i] >> tap) & 1u) ? base[i] + delta : TC_OOB;
+      } else {
+        const int hv = p.upsample ? p.h_in * 2 : p.h_in;
+        const int wv = p.upsample ? p.w_in * 2 : p.w_in;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          int iy = y[i] * p.stride + dy;
+          int ix = x[i] * p.stride + dx;
+          const bool v = ok[i] && iy >= 0 && iy < hv && ix >= 0 && ix < wv;
+          if (p.upsample) { iy >>= 1; ix >>= 1; }
+          const int64_t src = ((int64_t)f[i] * p.h_in + iy) * p.w_in + ix;
+          voff[i] = v ? (uint32_t)(src * p.lda * 2 + chunk * 16) : TC_OOB;
+        }
       }
     } else {  // CONVT3
-      const int hw = p.h_out * p.w_out;
       const int tap = k0 / p.cin;
-      const int c0 = k0 - tap * p.cin + chunk * 8;
-      const int dt = tap - 1;
+      soff = (uint32_t)(k0 - tap * p.cin) * 2u;
+      const uint32_t delta = (uint32_t)((tap - 1) * p.h_out * p.w_out * p.lda * 2);
 #pragma unroll
-      for (int i = 0; i < R; ++i) {
-        const int tt = y[i] + dt;
-        v[i] = ok[i] && tt >= 0 && tt < p.t_len;
-        const int64_t src = (int64_t)m[i] + (v[i] ? (int64_t)dt * hw : 0);
-        ra[i] = *reinterpret_cast<const u32x4*>(a_base + src * p.lda + c0);
-      }
+      for (int i = 0; i < R; ++i) voff[i] = ((vbits[i] >> tap) & 1u) ? base[i] + delta : TC_OOB;
     }
-    unsigned mask = 0;
-#pragma unroll
-    for (int i = 0; i < R; ++i) mask |= (v[i] && k_ok) ? (1u << i) : 0u;
-    return mask;
   }
 };
 
-template <int R>
-__device__ __forceinline__ void apply_mask(u32x4 (&r)[R], unsigned mask) {
-#pragma unroll
-  for (int i = 0; i < R; ++i) r[i] = mask4(r[i], (mask >> i) & 1u);
+// Host-side guard shared by the launchers: every byte offset a tile load can form must fit the
+// 31-bit range the out-of-range marker relies on.
+inline bool tc_gemm_offsets_fit(const TcGemmParams& p) {
+  int64_t a_rows = p.m;
+  if (p.gather == TC_GATHER_CONV3x3) a_rows = (int64_t)p.frames * p.h_in * p.w_in;
+  const int64_t a_bytes = a_rows * p.lda * 2;
+  const int64_t w_bytes = (int64_t)p.n * p.ldw * 2;
+  return a_bytes < 0x7fffff00LL && w_bytes < 0x7fffff00LL;
 }
 
 int tc_gemm_wide_try(const TcGemmParams& p, int batch, hipStream_t s, bool force);   // gemm_wide.hip; 1 = launched

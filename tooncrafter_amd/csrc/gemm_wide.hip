@@ -47,41 +47,35 @@ __global__ __launch_bounds__(WTHREADS, 2) void gemm_wide_kernel(const TcGemmPara
   if (tile_m >= tiles_m) return;
 
   const int64_t bz = blockIdx.z;
-  const bf16_t* __restrict__ a_base = reinterpret_cast<const bf16_t*>(p.a) + bz * p.stride_a;
-  const bf16_t* __restrict__ w_base = reinterpret_cast<const bf16_t*>(p.w) + bz * p.stride_w;
+  const tc_rsrc_t a_rsrc = make_rsrc(reinterpret_cast<const bf16_t*>(p.a) + bz * p.stride_a);
+  const tc_rsrc_t w_rsrc = make_rsrc(reinterpret_cast<const bf16_t*>(p.w) + bz * p.stride_w);
 
   const int lrow = tid >> 3;     // 0..63
   const int chunk = tid & 7;
   AGather<GATHER, RA> ag;
-  ag.init(p, tile_m * WBM, lrow, 64);
-  bool b_ok[RB];
-  const bf16_t* b_ptr[RB];
+  ag.init(p, tile_m * WBM, lrow, 64, chunk);
+  uint32_t b_voff[RB];
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
     const int n = tile_n * BN + lrow + 64 * i;
-    b_ok[i] = n < p.n;
-    b_ptr[i] = w_base + (int64_t)(b_ok[i] ? n : p.n - 1) * p.ldw;
+    b_voff[i] = n < p.n ? (uint32_t)((int64_t)n * p.ldw * 2 + chunk * 16) : TC_OOB;
   }
+  const bool k_ragged = (p.k & (TC_BK - 1)) != 0;
 
   u32x4 ra[RA], rb[RB];
-  unsigned amask = 0, bmask = 0;
-  unsigned b_okbits = 0;
-#pragma unroll
-  for (int i = 0; i < RB; ++i) b_okbits |= b_ok[i] ? (1u << i) : 0u;
   auto load_tile = [&](int kb) {
     const int k0 = kb * TC_BK;
-    const bool k_ok = k0 + chunk * 8 < p.k;
-    const int kc = k_ok ? k0 + chunk * 8 : 0;
+    uint32_t a_voff[RA], a_soff;
+    ag.offsets(p, k0, chunk, a_voff, a_soff);
+    const bool dead = k_ragged && (k0 + chunk * 8 >= p.k);
 #pragma unroll
-    for (int i = 0; i < RB; ++i) rb[i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + kc);
-    amask = ag.load(p, a_base, k0, chunk, ra);
-    bmask = k_ok ? b_okbits : 0u;
+    for (int i = 0; i < RB; ++i) rb[i] = buf_load16(w_rsrc, dead ? TC_OOB : b_voff[i], (uint32_t)k0 * 2u);
+#pragma unroll
+    for (int i = 0; i < RA; ++i) ra[i] = buf_load16(a_rsrc, dead ? TC_OOB : a_voff[i], a_soff);
   };
   auto store_tile = [&](int stage) {
     char* sa = smem + stage * STAGE_BYTES;
     char* sb = sa + WBM * TC_BK * 2;
-    apply_mask(ra, amask);
-    apply_mask(rb, bmask);
 #pragma unroll
     for (int i = 0; i < RA; ++i) *reinterpret_cast<u32x4*>(sa + lds_off(lrow + 64 * i, chunk)) = ra[i];
 #pragma unroll
@@ -99,24 +93,50 @@ __global__ __launch_bounds__(WTHREADS, 2) void gemm_wide_kernel(const TcGemmPara
   const int frow = lane & 31;
   const int fhalf = lane >> 5;
 
+  // fragment reads are double-buffered in registers where the budget allows (TNW <= 4): the ds_reads of
+  // K-slice kk+1 are in flight under the MFMAs of slice kk; sched_barrier pins that order
   auto compute = [&](int stage) {
     const char* sa = smem + stage * STAGE_BYTES;
     const char* sb = sa + WBM * TC_BK * 2;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    auto frags = [&](int kk, bf16x8 (&a)[2], bf16x8 (&b)[TNW]) {
       const int c = kk * 2 + fhalf;
-      bf16x8 af[2], bf[TNW];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        af[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(wm * 64 + i * 32 + frow, c));
+        a[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(wm * 64 + i * 32 + frow, c));
 #pragma unroll
       for (int j = 0; j < TNW; ++j)
-        bf[j] = *reinterpret_cast<const bf16x8*>(sb + lds_off(wn * WN + j * 32 + frow, c));
+        b[j] = *reinterpret_cast<const bf16x8*>(sb + lds_off(wn * WN + j * 32 + frow, c));
+    };
+    auto mfmas = [&](bf16x8 (&a)[2], bf16x8 (&b)[TNW]) {
 #pragma unroll
       for (int j = 0; j < TNW; ++j)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    };
+    if constexpr (TNW <= 4) {
+      bf16x8 af[2][2], bf[2][TNW];
+      frags(0, af[0], bf[0]);
+      frags(1, af[1], bf[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(af[0], bf[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      frags(2, af[0], bf[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(af[1], bf[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      frags(3, af[1], bf[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(af[0], bf[0]);
+      mfmas(af[1], bf[1]);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        bf16x8 af[2], bf[TNW];
+        frags(kk, af, bf);
+        mfmas(af, bf);
+      }
     }
   };
 
