@@ -70,3 +70,21 @@ if __name__ == "__main__":
     conv(32, 10, 16, 1280, 1280, "L2 tconv", t3=True)
     conv(16, 80, 128, 512, 512, "dec L2")
     conv(16, 320, 512, 128, 128, "dec L0")
+
+
+def attn(batch, heads, lq, lk, kv_bdiv=1, tag=""):
+    c = heads * 64
+    q = torch.randn(batch * lq, c, device=dev).to(BF)
+    kvb = (batch + kv_bdiv - 1) // kv_bdiv
+    kv = torch.randn(kvb * lk, 2 * c, device=dev).to(BF)
+    ms = timeit(lambda: hip.attention(q, kv[:, :c], kv[:, c:], batch=batch, heads=heads, lq=lq, lk=lk, kv_bdiv=kv_bdiv))
+    fl = 4.0 * batch * heads * lq * lk * 64
+    print(f"attn    {tag:14s} b={batch} h={heads} lq={lq} lk={lk}  {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF/s")
+
+
+if __name__ == "__main__":
+    attn(32, 5, 2560, 2560, tag="L0 self")
+    attn(32, 10, 640, 640, tag="L1 self")
+    attn(32, 5, 2560, 77, 16, tag="L0 text")
+    attn(32, 5, 2560, 16, 1, tag="L0 image")
+    attn(16, 8, 10240, 20480, 16, tag="dec L2 ref")

@@ -52,32 +52,51 @@ __global__ __launch_bounds__(256) void attn_d64_kernel(const TcAttnParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
 
-  const int n_tiles = (p.lk + KT - 1) / KT;
-  for (int kt = 0; kt < n_tiles; ++kt) {
+  // K/V tile staging: 64 keys x 64 d = 512 16-byte chunks per matrix, 2 per thread.  Lane-consecutive
+  // keys (idx & 63) make the transposed V^T writes 128-byte contiguous per d-row (conflict-free).
+  // The loads of tile kt+1 are issued before the MFMAs of tile kt and land in LDS after them, so the
+  // global latency hides under the compute instead of being exposed once per tile.
+  u32x4 kreg[2], vreg[2];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  auto load_kv = [&](int kt) {
     const int key0 = kt * KT;
-    __syncthreads();   // previous tile fully consumed
-    // ---- stage K (row-major) and V^T: 64 keys x 64 d = 512 16-byte chunks each, 2 per thread
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int idx = tid + it * 256;
-      const int key = idx & 63;        // lane-consecutive keys -> the 8 d-chunks of a key row sit 64 lanes apart
-      const int dch = idx >> 6;        // 0..7
+      const int key = idx & 63, dch = idx >> 6;
       const int gk = key0 + key;
-      u32x4 kv4 = {0u, 0u, 0u, 0u}, vv4 = {0u, 0u, 0u, 0u};
-      if (gk < p.lk) {
-        kv4 = *reinterpret_cast<const u32x4*>(kb + (int64_t)gk * p.k_ss + dch * 8);
-        vv4 = *reinterpret_cast<const u32x4*>(vb + (int64_t)gk * p.v_ss + dch * 8);
-      }
+      const int gkc = gk < p.lk ? gk : p.lk - 1;          // clamped address, zeroed at store time
+      kreg[it] = *reinterpret_cast<const u32x4*>(kb + (int64_t)gkc * p.k_ss + dch * 8);
+      vreg[it] = *reinterpret_cast<const u32x4*>(vb + (int64_t)gkc * p.v_ss + dch * 8);
+    }
+  };
+  auto store_kv = [&](int kt) {
+    const int key0 = kt * KT;
+    uint16_t* vt = reinterpret_cast<uint16_t*>(vts);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int idx = tid + it * 256;
+      const int key = idx & 63, dch = idx >> 6;
+      const bool ok = key0 + key < p.lk;
+      const u32x4 kv4 = ok ? kreg[it] : zero4;
+      const u32x4 vv4 = ok ? vreg[it] : zero4;
       *reinterpret_cast<u32x4*>(ks + key * K_STRIDE + dch * 16) = kv4;
-      // transpose V: element e of this chunk is d = dch*8 + e
-      uint16_t* vt = reinterpret_cast<uint16_t*>(vts);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         vt[(dch * 8 + 2 * e) * (VT_STRIDE / 2) + key] = (uint16_t)(vv4[e] & 0xffffu);
         vt[(dch * 8 + 2 * e + 1) * (VT_STRIDE / 2) + key] = (uint16_t)(vv4[e] >> 16);
       }
     }
+  };
+
+  const int n_tiles = (p.lk + KT - 1) / KT;
+  load_kv(0);
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    const int key0 = kt * KT;
+    __syncthreads();   // previous tile fully consumed
+    store_kv(kt);
     __syncthreads();
+    if (kt + 1 < n_tiles) load_kv(kt + 1);
 
     // ---- S^T = K Q^T : two 32-key blocks
     f32x16 st[2];
@@ -91,37 +110,46 @@ __global__ __launch_bounds__(256) void attn_d64_kernel(const TcAttnParams p) {
         st[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st[kbk], 0, 0, 0);
       }
     }
-    // lane owns query l31; st[kbk][r] is key  key0 + kbk*32 + (r&3) + 8*(r>>2) + 4*half
-    float mx = -1e30f;
+    // lane owns query l31; st[kbk][r] is key  key0 + kbk*32 + (r&3) + 8*(r>>2) + 4*half.
+    // The softmax is kept lean (it, not the MFMAs, bounds this kernel): masking only on the ragged
+    // last tile, the scale folded into one fma per element, and the O/l rescale skipped whenever no
+    // row of the wave raised its running maximum (exact: alpha would be 1).
+    if (key0 + KT > p.lk) {
+#pragma unroll
+      for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key0 + kbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          st[kbk][r] = key < p.lk ? st[kbk][r] : -1e30f;
+        }
+    }
+    float mx = st[0][0];
 #pragma unroll
     for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = key0 + kbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        float s = st[kbk][r] * c;
-        s = key < p.lk ? s : -1e30f;
-        st[kbk][r] = s;
-        mx = fmaxf(mx, s);
-      }
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kbk][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f(m_run - m_new);
+    const float m_new = fmaxf(m_run, mx * c);         // c > 0: max commutes with the scale
+    if (!__all(m_new == m_run)) {
+      const float alpha = exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+      m_run = m_new;
+    }
     float rs = 0.f;
 #pragma unroll
     for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = exp2f(st[kbk][r] - m_new);   // masked keys: exp2(-1e30 - m) = 0
+        const float pv = exp2f(fmaf(st[kbk][r], c, -m_run));   // masked keys: exp2(-huge) = 0
         st[kbk][r] = pv;
         rs += pv;
       }
     rs += __shfl_xor(rs, 32, 64);
-    l_run = l_run * alpha + rs;
-    m_run = m_new;
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+    l_run += rs;
 
     // ---- O^T += V^T P^T.  MFMA k-slot (half, j) of slab s in key block kbk carries key
     //      kbk*32 + 16 s + 8 (j>>2) + 4 half + (j&3)  -- for BOTH operands.

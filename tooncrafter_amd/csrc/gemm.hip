@@ -103,8 +103,10 @@ __device__ __forceinline__ void epilogue_fast(const TcGemmParams& p, const float
 #pragma unroll
       for (int e = 0; e < 4; ++e) { gt[e] = lo[e]; gt[4 + e] = hi[e]; }
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
-        x[e] = (x[e] * p.alpha + bv[e]) * gelu_erf_f(gt[e] * p.alpha + bg[e]) * p.out_scale;
+      for (int e = 0; e < 8; ++e) {
+        if (PLAIN) x[e] = (x[e] + bv[e]) * gelu_erf_f(gt[e] + bg[e]);
+        else x[e] = (x[e] * p.alpha + bv[e]) * gelu_erf_f(gt[e] * p.alpha + bg[e]) * p.out_scale;
+      }
     } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -295,7 +297,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams p) {
 
   const int n_out = p.act == TC_ACT_GEGLU ? p.n / 2 : p.n;
   if ((n_out & 7) != 0) epilogue_tail<BM, BN>(p, cs, tid, tile_m, tile_n, bz);
-  else if (TN == 2 && p.act == TC_ACT_GEGLU) epilogue_fast<true, BM, BN, false>(p, cs, tid, tile_m, tile_n, bz);
+  else if (TN == 2 && p.act == TC_ACT_GEGLU) {
+    if (p.alpha == 1.f && p.out_scale == 1.f) epilogue_fast<true, BM, BN, true>(p, cs, tid, tile_m, tile_n, bz);
+    else epilogue_fast<true, BM, BN, false>(p, cs, tid, tile_m, tile_n, bz);
+  }
   else if (p.alpha == 1.f && p.out_scale == 1.f && p.act == TC_ACT_NONE && !p.row_bias)
     epilogue_fast<false, BM, BN, true>(p, cs, tid, tile_m, tile_n, bz);
   else epilogue_fast<false, BM, BN, false>(p, cs, tid, tile_m, tile_n, bz);

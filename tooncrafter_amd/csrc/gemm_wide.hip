@@ -303,9 +303,10 @@ int tc_gemm_wide_try(const TcGemmParams& p, int batch, hipStream_t s, bool force
   const int tiles_n = (p.n + bn - 1) / bn;
   const int tiles_m = (p.m + WBM - 1) / WBM;
   const int64_t blocks = (int64_t)tiles_n * tiles_m * batch;
-  // measured on MI355X (profiles/r01_gemm_tile_sweep.txt): the 256-row tile wins only when there is
-  // enough K to amortise its single-block-per-CU prologue/epilogue and enough N to matter
-  if (!force && (blocks < 192 || p.n < 512 || p.k < 512)) return 0;
+  // measured on MI355X (profiles/r01_gemm_tile_sweep_v2.txt): the 256-row tile wins only when there is
+  // enough K to amortise its single-block-per-CU prologue/epilogue and enough N to matter (in this
+  // model: the decoder's 512-channel 3x3 convolutions)
+  if (!force && (blocks < 192 || p.n < 512 || p.k < 2048)) return 0;
   const int64_t nblk = (int64_t)tiles_n * 8 * ((tiles_m + 7) / 8);
   if (nblk > 0x7fffffffLL) return 0;
   dim3 grid((unsigned)nblk, 1, (unsigned)batch);
