@@ -266,6 +266,19 @@ def main():
             if args.ddim_steps == 50 else None,
             "output_finite": finite,
         }
+    if rank == 0:
+        # row f1 (not part of `value`): the first-stage encoder that produces z and the reference
+        # hidden states, 16 frames at 320x512, reported so that "with encoder" can be derived
+        frames = torch.rand((16, 3, 320, 512), device=device) * 2 - 1
+        with torch.no_grad():
+            model.first_stage_model.encode(frames, return_hidden_states=True)
+            torch.cuda.synchronize()
+            te = time.perf_counter()
+            model.first_stage_model.encode(frames, return_hidden_states=True)
+            torch.cuda.synchronize()
+        enc_ms = (time.perf_counter() - te) * 1e3
+        result["encoder_16f_ms"] = round(enc_ms, 2)
+        result["frames_per_s_with_encoder"] = round(16.0 / (dt / args.steps + enc_ms * 1e-3), 4)
     if rank == 0 and not args.no_roofline:
         result["roofline"] = measure_roofline(model, inp)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

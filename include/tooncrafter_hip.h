@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TC_ABI_VERSION 1
+#define TC_ABI_VERSION 2
 
 enum {
   TC_OK = 0,
@@ -75,6 +75,8 @@ typedef struct TcGemmParams {
   int32_t h_in, w_in;      /* source image size */
   int32_t stride;          /* 1 or 2 */
   int32_t upsample;        /* 1: source is nearest-upsampled x2 on the fly (Upsample + conv fused) */
+  int32_t pad;             /* leading (top/left) zero padding of the 3x3 gather: 1 = symmetric pad 1;
+                              0 = the VAE encoder's asymmetric (0,1,0,1) pad before its stride-2 conv */
   /* batching (blockIdx.z): element strides, 0 = shared */
   int32_t batch;
   int64_t stride_a, stride_w, stride_c;

@@ -41,7 +41,10 @@ class EmuOps:
             x = _f(a[:fr * hi * wi, :cin]).reshape(fr, hi, wi, cin).permute(0, 3, 1, 2)
             if conv.get("upsample", False):
                 x = F.interpolate(x, scale_factor=2, mode="nearest")
-            cols = F.unfold(x, kernel_size=3, padding=1, stride=conv.get("stride", 1))   # [fr, cin*9, L]
+            if conv.get("pad", 1) == 0:
+                cols = F.unfold(F.pad(x, (0, 1, 0, 1)), kernel_size=3, padding=0, stride=conv.get("stride", 1))
+            else:
+                cols = F.unfold(x, kernel_size=3, padding=1, stride=conv.get("stride", 1))   # [fr, cin*9, L]
             cols = cols.reshape(fr, cin, 9, ho * wo).permute(0, 3, 2, 1)                 # [fr, L, tap, cin]
             return cols.reshape(fr * ho * wo, 9 * cin)
         t = conv["t_len"]

@@ -177,10 +177,16 @@ def main():
     with torch.device("meta"):
         from lvdm.modules.networks.openaimodel3d import UNetModel
         from lvdm.models.autoencoder_dualref import VideoDecoder
+        from lvdm.modules.networks.ae_modules import Encoder
         un = UNetModel(**fp.unet_config.params)
         vd = VideoDecoder(**fp.first_stage_config.params.ddconfig)
+        en = Encoder(**fp.first_stage_config.params.ddconfig)
     man["full"] = {**{"model.diffusion_model." + k: v for k, v in manifest(un).items()},
-                   **{"first_stage_model.decoder." + k: v for k, v in manifest(vd).items()}}
+                   **{"first_stage_model.decoder." + k: v for k, v in manifest(vd).items()},
+                   **{"first_stage_model.encoder." + k: v for k, v in manifest(en).items()},
+                   "first_stage_model.quant_conv.weight": [8, 8, 1, 1], "first_stage_model.quant_conv.bias": [8],
+                   "first_stage_model.post_quant_conv.weight": [4, 4, 1, 1],
+                   "first_stage_model.post_quant_conv.bias": [4]}
     man["full_buffers"] = {k: list(v.shape) for k, v in model.named_buffers()
                            if not k.startswith(("first_stage_model", "model."))}
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
@@ -216,6 +222,18 @@ def main():
                         **{f"ref{i}": r.numpy() for i, r in enumerate(ref_ctx)},
                         dec=dec.numpy(), dec_first_stage=dec2.numpy(), n_params=np.int64(nd))
     print("decoder_tiny.npz written; out std", float(dec.std()), "params", nd)
+
+    # ---------------------------------------------------------------- tiny encoder (row f1)
+    ge = torch.Generator().manual_seed(31)
+    frames = torch.randn(3, 3, 32, 48, generator=ge).clamp(-1, 1)
+    post, hidden = model.first_stage_model.encode(frames, return_hidden_states=True)
+    enoise = torch.randn(post.mean.shape, generator=ge)
+    zs = model.scale_factor * post.sample(noise=enoise)      # get_first_stage_encoding (ddpm3d.py:610-618) with injected noise
+    ne = sum(p.numel() for p in model.first_stage_model.encoder.parameters())
+    np.savez_compressed(os.path.join(HERE, "encoder_tiny.npz"), frames=frames.numpy(), noise=enoise.numpy(),
+                        mean=post.mean.numpy(), logvar=post.logvar.numpy(), z=zs.numpy(),
+                        **{f"hid{i}": h.numpy() for i, h in enumerate(hidden)}, n_params=np.int64(ne))
+    print("encoder_tiny.npz written; z std", float(zs.std()), "params", ne)
 
     # ---------------------------------------------------------------- tiny DDIM trajectory
     S = 5

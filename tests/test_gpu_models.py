@@ -132,8 +132,7 @@ def _tiny_pipeline(tiny_sd):
     from tooncrafter_amd.utils import instantiate_from_config
     model = instantiate_from_config(dict(target="lvdm.models.ddpm3d.LatentVisualDiffusion",
                                          params=_tiny_model_cfg())).eval()
-    sd = {k: v for k, v in tiny_sd.items() if k.startswith(("model.diffusion_model.", "first_stage_model.decoder."))}
-    model.load_state_dict(sd, strict=False)
+    model.load_state_dict(tiny_sd, strict=False)
     return model.to(DEV)
 
 
@@ -224,3 +223,19 @@ def test_unet_full_size_vs_contract(hip, manifest):
     print(f"full-size UNet (B=2): HIP vs emulated contract rel-L2 {e:.3e}; out std {float(y.std()):.3f}")
     assert torch.isfinite(y).all()
     assert e < 3e-2
+
+
+def test_encoder_tiny_vs_reference_golden(hip, tiny_sd):
+    """Row f1: encode (Encoder + fused quant_conv) -> posterior + the five hidden states."""
+    from tooncrafter_amd.lvdm.autoencoder import AutoencoderKL_Dualref
+    g = load_golden("encoder_tiny.npz")
+    ae = AutoencoderKL_Dualref(ddconfig=dict(TINY_DD_CFG), embed_dim=4).eval()
+    ae.load_state_dict(sub_state_dict(tiny_sd, "first_stage_model."), strict=True)
+    ae.to(DEV)
+    with torch.no_grad():
+        post, hidden = _with_backend(hip, lambda: ae.encode(torch.from_numpy(g["frames"]).to(DEV), return_hidden_states=True))
+    z = 0.18215 * post.sample(noise=torch.from_numpy(g["noise"]))
+    errs = [rel_l2(h.cpu(), torch.from_numpy(g[f"hid{i}"])) for i, h in enumerate(hidden)]
+    ez = rel_l2(z.cpu(), torch.from_numpy(g["z"]))
+    print(f"tiny encoder: z rel-L2 {ez:.3e}; hidden states", [f"{e:.3e}" for e in errs])
+    assert ez < 3e-2 and max(errs) < 3e-2

@@ -27,16 +27,17 @@ def _load(module, sd):
 
 
 def test_state_dict_keys_match_reference_full(manifest):
-    from tooncrafter_amd.lvdm.autoencoder_dualref import VideoDecoder
+    from tooncrafter_amd.lvdm.autoencoder import AutoencoderKL_Dualref
     from tooncrafter_amd.lvdm.openaimodel3d import UNetModel
     with torch.device("meta"):
         un = UNetModel(**FULL_UNET_CFG)
-        vd = VideoDecoder(**FULL_DD_CFG)
+        ae = AutoencoderKL_Dualref(ddconfig=dict(FULL_DD_CFG), embed_dim=4)
     mine = {"model.diffusion_model." + k: list(v.shape) for k, v in un.named_parameters()}
-    mine.update({"first_stage_model.decoder." + k: list(v.shape) for k, v in vd.named_parameters()})
+    mine.update({"first_stage_model." + k: list(v.shape) for k, v in ae.named_parameters()})
     assert mine == manifest["full"]
-    assert sum(p.numel() for p in un.parameters()) == 1438854980      # SURVEY 8c structural KAT
-    assert sum(p.numel() for p in vd.parameters()) == 65778223
+    assert sum(p.numel() for p in un.parameters()) == 1438854980      # SURVEY 8c structural KATs
+    assert sum(p.numel() for p in ae.decoder.parameters()) == 65778223
+    assert sum(p.numel() for p in ae.encoder.parameters()) == 34163592
 
 
 def test_unet_tiny_host_logic(tiny_sd, emu_fp32):
@@ -90,11 +91,9 @@ def test_ddim_tiny_trajectory_host_logic(tiny_sd, emu_fp32):
     from tooncrafter_amd.utils import instantiate_from_config
     g = load_golden("ddim_tiny.npz")
     model = instantiate_from_config(dict(target="lvdm.models.ddpm3d.LatentVisualDiffusion", params=_tiny_model_cfg())).eval()
-    sd = {k: v for k, v in tiny_sd.items() if k.startswith(("model.diffusion_model.", "first_stage_model.decoder."))}
-    missing, unexpected = model.load_state_dict(sd, strict=False)
+    missing, unexpected = model.load_state_dict(tiny_sd, strict=False)     # every reference parameter has a home
     assert not unexpected
-    assert all(m.startswith(("first_stage_model.quant_conv", "first_stage_model.post_quant_conv")) or
-               m in dict(model.named_buffers()) for m in missing), missing
+    assert all(m in dict(model.named_buffers()) for m in missing), missing   # only the schedule buffers
     # schedule buffers equal the reference's, bit for bit
     gs = load_golden("schedule.npz")
     for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
@@ -146,3 +145,21 @@ def test_step_scalars_first_step_is_finite():
     for i in range(50):
         r = float(gs["s50_trailing_radicand_f32"][i])
         assert abs(s.step_scalars(i, int(s.ddim_timesteps[i]))["dir_coef"] - np.sqrt(np.float32(r))) < 1e-7
+
+
+def test_encoder_tiny_host_logic(tiny_sd, emu_fp32):
+    """Row f1: AutoencoderKL_Dualref.encode (Encoder + fused quant_conv + posterior) vs the reference."""
+    from tooncrafter_amd.lvdm.autoencoder import AutoencoderKL_Dualref
+    g = load_golden("encoder_tiny.npz")
+    ae = AutoencoderKL_Dualref(ddconfig=dict(TINY_DD_CFG), embed_dim=4).eval()
+    missing, unexpected = ae.load_state_dict(sub_state_dict(tiny_sd, "first_stage_model."), strict=True), None
+    with torch.no_grad():
+        post, hidden = ae.encode(torch.from_numpy(g["frames"]), return_hidden_states=True)
+        z = 0.18215 * post.sample(noise=torch.from_numpy(g["noise"]))
+    assert rel_l2(post.mean, torch.from_numpy(g["mean"])) < 3e-2
+    assert rel_l2(z, torch.from_numpy(g["z"])) < 3e-2
+    assert len(hidden) == 5
+    for i, h in enumerate(hidden):
+        ref = torch.from_numpy(g[f"hid{i}"])
+        assert h.shape == ref.shape
+        assert rel_l2(h, ref) < 3e-2, i

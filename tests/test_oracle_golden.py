@@ -90,3 +90,19 @@ def test_ddim_tiny_trajectory_matches_reference(tiny_sd):
     for i, p in enumerate(x0s):
         assert rel_l2(p, torch.from_numpy(g["pred_x0"][i])) < 1e-4, i
     assert rel_l2(out, torch.from_numpy(g["samples"])) < 1e-4
+
+
+def test_encoder_tiny_matches_reference(tiny_sd):
+    from oracle import encoder as oenc
+    g = load_golden("encoder_tiny.npz")
+    sd = sub_state_dict(tiny_sd, "first_stage_model.")
+    assert sum(v.numel() for k, v in sd.items() if k.startswith("encoder.")) == int(g["n_params"])
+    z, mean, logvar, hidden = oenc.encode(sd, torch.from_numpy(g["frames"]), noise=torch.from_numpy(g["noise"]))
+    assert rel_l2(mean, torch.from_numpy(g["mean"])) < 2e-5
+    assert rel_l2(logvar, torch.from_numpy(g["logvar"])) < 2e-5
+    assert rel_l2(z, torch.from_numpy(g["z"])) < 2e-5
+    assert len(hidden) == 5
+    for i, h in enumerate(hidden):
+        assert rel_l2(h, torch.from_numpy(g[f"hid{i}"])) < 2e-5, i
+    fl = oenc.first_last_hidden(hidden, t=3)
+    assert [tuple(x.shape[:3]) for x in fl] == [(1, 64, 2), (1, 128, 2), (1, 256, 2), (1, 256, 2), (1, 64, 2)]

@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libtooncrafter_hip.so")
 
-TC_ABI_VERSION = 1
+TC_ABI_VERSION = 2
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_GEGLU = 0, 1, 2, 3
 GATHER_LINEAR, GATHER_CONV3x3, GATHER_CONVT3 = 0, 1, 2
 
@@ -30,7 +30,7 @@ class TcGemmParams(C.Structure):
         ("act", C.c_int32), ("out_f32", C.c_int32),
         ("gather", C.c_int32), ("cin", C.c_int32), ("frames", C.c_int32), ("t_len", C.c_int32),
         ("h_out", C.c_int32), ("w_out", C.c_int32), ("h_in", C.c_int32), ("w_in", C.c_int32),
-        ("stride", C.c_int32), ("upsample", C.c_int32),
+        ("stride", C.c_int32), ("upsample", C.c_int32), ("pad", C.c_int32),
         ("batch", C.c_int32),
         ("stride_a", C.c_int64), ("stride_w", C.c_int64), ("stride_c", C.c_int64),
     ]

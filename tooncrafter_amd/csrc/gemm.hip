@@ -340,7 +340,10 @@ extern "C" int tc_gemm_bf16(const TcGemmParams* pp, void* stream) {
       if (p.h_in <= 0 || p.w_in <= 0 || (p.stride != 1 && p.stride != 2)) return TC_ESHAPE;
       if (p.upsample && p.stride != 1) return TC_ESHAPE;
       const int hvv = p.upsample ? 2 * p.h_in : p.h_in, wvv = p.upsample ? 2 * p.w_in : p.w_in;
-      if ((hvv + 2 - 3) / p.stride + 1 != p.h_out || (wvv + 2 - 3) / p.stride + 1 != p.w_out) return TC_ESHAPE;
+      if (p.pad != 0 && p.pad != 1) return TC_ESHAPE;
+      // pad = 1: symmetric padding 1; pad = 0: one trailing row/column of zeros only (0,1,0,1)
+      const int extra = p.pad == 1 ? 2 : 1;
+      if ((hvv + extra - 3) / p.stride + 1 != p.h_out || (wvv + extra - 3) / p.stride + 1 != p.w_out) return TC_ESHAPE;
     } else {
       if (p.t_len <= 0 || (p.frames % p.t_len) != 0) return TC_ESHAPE;
     }

@@ -49,7 +49,9 @@ struct AGather {
   int f[R], y[R], x[R];  // generic 3x3 path (stride 2 / fused upsample) only
   bool ok[R];
 
-  __device__ __forceinline__ bool fast3x3(const TcGemmParams& p) const { return p.stride == 1 && !p.upsample; }
+  __device__ __forceinline__ bool fast3x3(const TcGemmParams& p) const {
+    return p.stride == 1 && !p.upsample && p.pad == 1;
+  }
 
   __device__ __forceinline__ void init(const TcGemmParams& p, int tile_row0, int lrow, int row_step, int chunk) {
     const int hw = p.h_out * p.w_out;
@@ -93,7 +95,7 @@ struct AGather {
     } else if (GATHER == TC_GATHER_CONV3x3) {
       const int tap = k0 / p.cin;
       soff = (uint32_t)(k0 - tap * p.cin) * 2u;
-      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+      const int dy = tap / 3 - p.pad, dx = tap - (tap / 3) * 3 - p.pad;
       if (fast3x3(p)) {
         const uint32_t delta = (uint32_t)((dy * p.w_in + dx) * p.lda * 2);
 #pragma unroll

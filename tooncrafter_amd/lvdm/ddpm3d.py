@@ -185,6 +185,18 @@ class LatentDiffusion(DDPM):
         z = encoder_posterior.sample(noise=noise) if hasattr(encoder_posterior, "sample") else encoder_posterior
         return self.scale_factor * z
 
+    @torch.no_grad()
+    def encode_first_stage(self, x):
+        """ddpm3d.py:620-644: (B, 3, T, H, W) or (N, 3, H, W) pixels -> scaled latent.  All frames go
+        through the encoder in one call (the reference's perframe_ae loop computes the same thing one
+        frame at a time to save memory; 288 GB make that unnecessary)."""
+        if x.dim() == 5:
+            b, c, t, h, w = x.shape
+            frames = x.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w)
+            z = self.get_first_stage_encoding(self.first_stage_model.encode(frames)).detach()
+            return z.reshape(b, t, *z.shape[1:]).permute(0, 2, 1, 3, 4)
+        return self.get_first_stage_encoding(self.first_stage_model.encode(x)).detach()
+
     # ------------------------------------------------------------------ hot path
     def apply_model(self, x_noisy, t, cond, **kwargs):
         if not isinstance(cond, dict):

@@ -89,6 +89,7 @@ class HipOps:
             p.h_in, p.w_in = conv.get("h_in", conv["h_out"]), conv.get("w_in", conv["w_out"])
             p.stride = conv.get("stride", 1)
             p.upsample = 1 if conv.get("upsample", False) else 0
+            p.pad = conv.get("pad", 1)
             mm = p.frames * p.h_out * p.w_out
             need_rows = p.frames * p.h_in * p.w_in
             if a.shape[0] < need_rows:
