@@ -7,14 +7,17 @@
 // convolution tap is just a different source row for the same K-slice of channels.
 //
 // Tiling (wave64): block tile 128x128x64, 4 waves as 2x2, each wave 64x64 = 2x2
-// v_mfma_f32_32x32x16_bf16 sub-tiles (64 fp32 accumulators / lane).  A and B tiles are
-// register-staged (global_load_dwordx4 -> ds_write_b128) into a double-buffered LDS image
-// whose 16-byte chunks are XOR-swizzled by (row>>1)&7, which makes every ds_read_b128 lane
-// group of the MFMA fragment reads conflict-free (MI355X_MICROARCH.md, LDS table).  The
-// loads of tile k+1 are issued before the MFMAs of tile k and written after them, one
-// barrier per K-step.  All tile loads are branch-free: out-of-range rows / taps / K-tails
-// read a clamped in-bounds address and are zeroed by a select, so the eight loads of a
-// K-step always issue back to back (a per-load branch makes hipcc serialise them).
+// v_mfma_f32_32x32x16_bf16 sub-tiles (64 fp32 accumulators / lane).  A and B tiles travel
+// global -> LDS directly (buffer_load_dwordx4 ... lds, 1 KiB = 8 tile rows per wave
+// instruction; no staging registers, no ds_write pass) into a double-buffered LDS image whose
+// 16-byte chunks are XOR-swizzled by (row>>1)&7 -- applied on the source side of the DMA --
+// which makes every ds_read_b128 lane group of the MFMA fragment reads conflict-free
+// (MI355X_MICROARCH.md, LDS table).  The loads of tile k+1 are issued before the MFMAs of
+// tile k, one vmcnt wait + barrier per K-step.  All tile loads are branch-free: out-of-range
+// rows / taps / K-tails carry an out-of-range buffer offset and the hardware writes zeros.
+// Measured (profiles/r01_v6_gemm_ablation.txt): replacing the register-staged loads by the
+// DMA form is worth +9 % on the UNet; with it the K loop is bound by LDS/L1 traffic per FLOP
+// of the 128x128 tile (loads alone and MFMAs alone each take ~65 % of the full loop).
 // The epilogue transposes the accumulators through LDS (fp32) so the bias / embedding /
 // activation / residual / GEGLU math and the global stores run on 16-byte row vectors, with
 // a fully unrolled, unconditional fast path for whole vectors.  Blocks are numbered so that
@@ -163,12 +166,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams p) {
   constexpr int EPI_BYTES = BM * BN * 4;
   constexpr int SMEM_BYTES = 2 * STAGE_BYTES > EPI_BYTES ? 2 * STAGE_BYTES : EPI_BYTES;
   constexpr int RA = BM / 32, RB = BN / 32;                             // loader rows per thread
-  __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];       // reused by the epilogue
+  __shared__ __attribute__((aligned(1024))) char smem[SMEM_BYTES];     // reused by the epilogue
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // same value, provably wave-uniform (LDS-DMA base goes in M0)
 
   const int tiles_n = (p.n + BN - 1) / BN;
   const int tiles_m = (p.m + BM - 1) / BM;
@@ -183,8 +187,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams p) {
   const tc_rsrc_t w_rsrc = make_rsrc(reinterpret_cast<const bf16_t*>(p.w) + bz * p.stride_w);
 
   // ---- loader geometry: thread -> (row lrow + 32 i, 16-byte chunk) of both tiles
+  // The tile goes global -> LDS directly (buffer_load_dwordx4 ... lds).  One wave instruction fills
+  // 1 KiB = 8 tile rows, lane l landing at byte 16 l of the piece, i.e. at (row l>>3, physical chunk
+  // l&7): the XOR swizzle is therefore applied to the SOURCE -- the lane fetches the logical chunk whose
+  // swizzled home is its own slot.  (row>>1)&7 does not depend on i because rows step by 32.
   const int lrow = tid >> 3;
-  const int chunk = tid & 7;
+  const int chunk = (tid & 7) ^ ((lrow >> 1) & 7);
   AGather<GATHER, RA> ag;
   ag.init(p, tile_m * BM, lrow, 32, chunk);
   uint32_t b_voff[RB];
@@ -195,28 +203,23 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams p) {
   }
   const bool k_ragged = (p.k & (BK - 1)) != 0;      // linear layers only (conv K is a multiple of 64)
 
-  u32x4 ra[RA], rb[RB];
-
-  // issue the buffer loads of K-step kb: scalar K offset, per-lane row offsets fixed for the whole
-  // block, out-of-range rows return zeros -- nothing here costs VALU in the steady state
-  auto load_tile = [&](int kb) {
+  // issue the loads of K-step kb into `stage`: scalar K offset, per-lane row offsets fixed for the whole
+  // block, out-of-range rows / taps / K-tails write zeros -- no staging registers, no ds_write pass, and
+  // nothing here costs VALU in the steady state
+  auto load_tile = [&](int kb, int stage) {
     const int k0 = kb * BK;
     uint32_t a_voff[RA], a_soff;
     ag.offsets(p, k0, chunk, a_voff, a_soff);
-    const bool dead = k_ragged && (k0 + chunk * 8 >= p.k);   // this thread's chunk lies beyond K
-#pragma unroll
-    for (int i = 0; i < RB; ++i) rb[i] = buf_load16(w_rsrc, dead ? TC_OOB : b_voff[i], (uint32_t)k0 * 2u);
-#pragma unroll
-    for (int i = 0; i < RA; ++i) ra[i] = buf_load16(a_rsrc, dead ? TC_OOB : a_voff[i], a_soff);
-  };
-
-  auto store_tile = [&](int stage) {
-    char* sa = smem + stage * STAGE_BYTES;
+    // OR-ing TC_OOB into an offset keeps it out of range: a K-tail chunk is zero-filled without a branch
+    const uint32_t kill = (k_ragged && (k0 + chunk * 8 >= p.k)) ? TC_OOB : 0u;
+    char* sa = smem + stage * STAGE_BYTES + wave_u * 1024;
     char* sb = sa + BM * BK * 2;
 #pragma unroll
-    for (int i = 0; i < RA; ++i) *reinterpret_cast<u32x4*>(sa + lds_off(lrow + 32 * i, chunk)) = ra[i];
+    for (int i = 0; i < RB; ++i)
+      glds16(w_rsrc, sb + i * 4096, b_voff[i] | kill, (uint32_t)k0 * 2u);
 #pragma unroll
-    for (int i = 0; i < RB; ++i) *reinterpret_cast<u32x4*>(sb + lds_off(lrow + 32 * i, chunk)) = rb[i];
+    for (int i = 0; i < RA; ++i)
+      glds16(a_rsrc, sa + i * 4096, a_voff[i] | kill, a_soff);
   };
 
   f32x16 acc[TM][TN];
@@ -269,15 +272,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
+  // LDS-DMA data is visible to a ds_read only after the issuing wave's vmcnt wait AND a barrier the
+  // reader has passed (MI355X_MICROARCH.md); the same barrier also retires the reads of the stage the
+  // next iteration overwrites.
   const int nk = (p.k + BK - 1) / BK;
-  load_tile(0);
-  store_tile(0);
+  load_tile(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int kb = 0; kb < nk; ++kb) {
-    const bool more = kb + 1 < nk;
-    if (more) load_tile(kb + 1);
+    if (kb + 1 < nk) load_tile(kb + 1, (kb + 1) & 1);
     compute(kb & 1);
-    if (more) store_tile((kb + 1) & 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 

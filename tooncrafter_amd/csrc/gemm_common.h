@@ -41,6 +41,14 @@ __device__ __forceinline__ u32x4 buf_load16(tc_rsrc_t rsrc, uint32_t voff, uint3
   return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
 }
 
+// Direct global -> LDS load of one 1-KiB piece per wave instruction (buffer_load_dwordx4 ... lds):
+// lane l's 16 bytes land at lds + 16 l.  `lds` must be wave-uniform (it travels in M0).  Out-of-range
+// offsets write zeros, like the register form.  Kept in a __device__ function: the host pass of hipcc
+// silently drops a __global__ template that names this builtin directly.
+__device__ __forceinline__ void glds16(tc_rsrc_t rsrc, char* lds, uint32_t voff, uint32_t soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+
 // Per-thread gather state for `R` rows of the A tile.
 template <int GATHER, int R>
 struct AGather {

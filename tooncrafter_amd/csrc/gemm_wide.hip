@@ -8,8 +8,8 @@
 // tile writes 2.2x fewer LDS bytes per FLOP and reads 0.7 fragments per MFMA instead of 1.0, and
 // BN = 320 divides every UNet width (320*k) exactly, so the N=320/960 layers of the highest
 // resolution stop wasting 17 % of their MFMAs on padding columns.
-// Pipeline: register-staged double-buffered LDS (2 x 72 KiB at BN=320), loads of K-step k+1 in
-// flight under the 40 MFMAs per wave of K-step k, one barrier per K-step.  Epilogue: each wave
+// Pipeline: double-buffered LDS (2 x 72 KiB at BN=320) filled by direct global->LDS loads, the loads
+// of K-step k+1 in flight under the 40 MFMAs per wave of K-step k, one barrier per K-step.  Epilogue: each wave
 // transposes its accumulators through a private 10 KiB LDS slab, 16 rows at a time, and finishes
 // on 16-byte row vectors (bias / row-bias / activation / GEGLU / residual / store).
 #include "gemm_common.h"
@@ -31,12 +31,13 @@ __global__ __launch_bounds__(WTHREADS, 2) void gemm_wide_kernel(const TcGemmPara
   constexpr int RA = WBM / 64, RB = BN / 64;           // loader rows per thread (64 rows per pass)
   constexpr int SLAB_FLOATS = 16 * WN;                 // per-wave epilogue slab: 16 rows x WN cols
   static_assert(8 * SLAB_FLOATS * 4 <= 2 * STAGE_BYTES, "epilogue slabs must fit in the pipeline buffers");
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // wave-uniform copy: LDS-DMA bases travel in M0
 
   const int tiles_n = (p.n + BN - 1) / BN;
   const int tiles_m = (p.m + WBM - 1) / WBM;
@@ -50,8 +51,11 @@ __global__ __launch_bounds__(WTHREADS, 2) void gemm_wide_kernel(const TcGemmPara
   const tc_rsrc_t a_rsrc = make_rsrc(reinterpret_cast<const bf16_t*>(p.a) + bz * p.stride_a);
   const tc_rsrc_t w_rsrc = make_rsrc(reinterpret_cast<const bf16_t*>(p.w) + bz * p.stride_w);
 
+  // tile loads go global -> LDS directly (buffer_load_dwordx4 ... lds, see gemm.hip): lane l of a wave
+  // instruction lands at byte 16 l of a 1-KiB piece = (row l>>3, physical chunk l&7) of 8 tile rows, so
+  // the XOR swizzle is applied to the source chunk the lane fetches
   const int lrow = tid >> 3;     // 0..63
-  const int chunk = tid & 7;
+  const int chunk = (tid & 7) ^ ((lrow >> 1) & 7);
   AGather<GATHER, RA> ag;
   ag.init(p, tile_m * WBM, lrow, 64, chunk);
   uint32_t b_voff[RB];
@@ -62,24 +66,18 @@ __global__ __launch_bounds__(WTHREADS, 2) void gemm_wide_kernel(const TcGemmPara
   }
   const bool k_ragged = (p.k & (TC_BK - 1)) != 0;
 
-  u32x4 ra[RA], rb[RB];
-  auto load_tile = [&](int kb) {
+  auto load_tile = [&](int kb, int stage) {
     const int k0 = kb * TC_BK;
     uint32_t a_voff[RA], a_soff;
     ag.offsets(p, k0, chunk, a_voff, a_soff);
-    const bool dead = k_ragged && (k0 + chunk * 8 >= p.k);
-#pragma unroll
-    for (int i = 0; i < RB; ++i) rb[i] = buf_load16(w_rsrc, dead ? TC_OOB : b_voff[i], (uint32_t)k0 * 2u);
-#pragma unroll
-    for (int i = 0; i < RA; ++i) ra[i] = buf_load16(a_rsrc, dead ? TC_OOB : a_voff[i], a_soff);
-  };
-  auto store_tile = [&](int stage) {
-    char* sa = smem + stage * STAGE_BYTES;
+    // OR-ing TC_OOB into an offset keeps it out of range: K-tail chunks are zero-filled without a branch
+    const uint32_t kill = (k_ragged && (k0 + chunk * 8 >= p.k)) ? TC_OOB : 0u;
+    char* sa = smem + stage * STAGE_BYTES + wave_u * 1024;
     char* sb = sa + WBM * TC_BK * 2;
 #pragma unroll
-    for (int i = 0; i < RA; ++i) *reinterpret_cast<u32x4*>(sa + lds_off(lrow + 64 * i, chunk)) = ra[i];
+    for (int i = 0; i < RB; ++i) glds16(w_rsrc, sb + i * 8192, b_voff[i] | kill, (uint32_t)k0 * 2u);
 #pragma unroll
-    for (int i = 0; i < RB; ++i) *reinterpret_cast<u32x4*>(sb + lds_off(lrow + 64 * i, chunk)) = rb[i];
+    for (int i = 0; i < RA; ++i) glds16(a_rsrc, sa + i * 8192, a_voff[i] | kill, a_soff);
   };
 
   f32x16 acc[2][TNW];
@@ -140,15 +138,16 @@ __global__ __launch_bounds__(WTHREADS, 2) void gemm_wide_kernel(const TcGemmPara
     }
   };
 
+  // LDS-DMA data is visible to a ds_read only after the issuing wave's vmcnt wait AND a barrier the
+  // reader has passed; the same barrier retires the reads of the stage the next iteration overwrites.
   const int nk = (p.k + TC_BK - 1) / TC_BK;
-  load_tile(0);
-  store_tile(0);
+  load_tile(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int kb = 0; kb < nk; ++kb) {
-    const bool more = kb + 1 < nk;
-    if (more) load_tile(kb + 1);
+    if (kb + 1 < nk) load_tile(kb + 1, (kb + 1) & 1);
     compute(kb & 1);
-    if (more) store_tile((kb + 1) & 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
