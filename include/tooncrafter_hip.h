@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TC_ABI_VERSION 2
+#define TC_ABI_VERSION 3
 
 enum {
   TC_OK = 0,
@@ -155,6 +155,12 @@ int tc_silu_f32_to_bf16(const float* x, tc_bf16* y, int64_t n, void* stream);
 int tc_time_mix3(const float* rows, int32_t ld, const float* w, const float* bias, float* out,
                  int32_t b, int32_t t, int32_t hw, void* stream);
 
+/* Output path, replaces scripts/evaluation/inference.py:148-153 on the device:
+ * clamp(x, -1, 1) -> (x + 1) / 2 -> (* 255) -> uint8 (truncation) with the permute (c t h w) -> (t h w c),
+ * for each of the b clips of x (b, 3, t, h, w) fp32; out is (b, t, h, w, 3) uint8.  Same fp32 operations in
+ * the same order as the reference, so the bytes are identical; it makes the rank-0 gather 4x smaller. */
+int tc_video_to_u8(const float* x, uint8_t* out, int32_t b, int32_t t, int32_t hw, void* stream);
+
 typedef struct TcDdimParams {
   const float* x;        /* current latent (B, n) fp32 */
   const float* e_cond;   /* UNet output for the conditional pass (B, n) */
@@ -165,10 +171,16 @@ typedef struct TcDdimParams {
   float cfg_scale, guidance_rescale;
   /* fp32 scalars in the reference's order of operations (ddim.py:251-277, ddpm3d.py:240-252) */
   float sqrt_ac, sqrt_1m_ac, sqrt_a_prev, dir_coef /* sqrt(1-a_prev-sigma^2) */, sigma, x0_rescale;
+  /* ABI 3 -- three-way guidance of samplers/ddim_multiplecond.py:226-236: when e_uncond_img is not NULL the
+   * combination is e_uncond + cfg_img*(e_uncond_img - e_uncond) + cfg_scale*(e_cond - e_uncond_img)
+   * (e_uncond_img = UNet pass with the image condition kept and the text dropped) */
+  const float* e_uncond_img;
+  float cfg_img;
 } TcDdimParams;
 
 /* CFG combine + rescale_noise_cfg (unbiased std over each sample) + v->(eps,x0) + dynamic
- * rescale + x_prev, fused.  Replaces ddim.py:226-277 and utils_diffusion.py:147-158.
+ * rescale + x_prev, fused.  Replaces ddim.py:226-277 / ddim_multiplecond.py:226-288 and
+ * utils_diffusion.py:147-158.
  * workspace: b * 64 * 4 doubles. */
 int64_t tc_ddim_workspace(int32_t b);
 int tc_ddim_step(const TcDdimParams* p, void* workspace, int64_t workspace_bytes, void* stream);

@@ -10,6 +10,7 @@ Restates (reference paths under lvdm/):
   models/samplers/ddim.py:24-57       DDIMSampler.make_schedule
   models/samplers/ddim.py:135-203     ddim_sampling
   models/samplers/ddim.py:206-279     p_sample_ddim
+  models/samplers/ddim_multiplecond.py:210-288   p_sample_ddim with three-way guidance (row f3)
   models/utils_diffusion.py:147-158   rescale_noise_cfg (unbiased std)
   models/ddpm3d.py:240-252            predict_start_from_z_and_v / predict_eps_from_z_and_v
 
@@ -100,15 +101,22 @@ def rescale_noise_cfg(cfg: torch.Tensor, pred_text: torch.Tensor, guidance_resca
 
 def ddim_step(x: torch.Tensor, e_cond: torch.Tensor, e_uncond: Optional[torch.Tensor], t: int, index: int,
               tab: Dict[str, object], buffers: Dict[str, torch.Tensor], cfg_scale: float,
-              guidance_rescale: float, noise: Optional[torch.Tensor]):
+              guidance_rescale: float, noise: Optional[torch.Tensor],
+              e_uncond_img: Optional[torch.Tensor] = None, cfg_img: Optional[float] = None):
     """One p_sample_ddim update (v-parameterisation, dynamic rescale).
+    With `e_uncond_img` (UNet pass that keeps the image condition and drops the text) the guidance
+    is the three-way form of ddim_multiplecond.py:226-236; `cfg_img=None` means `cfg_scale` (:217-218).
     Returns (x_prev, pred_x0)."""
     b = x.shape[0]
     size = (b,) + (1,) * (x.dim() - 1)
     if e_uncond is None or cfg_scale == 1.0:
         out = e_cond
     else:
-        out = e_uncond + cfg_scale * (e_cond - e_uncond)
+        if e_uncond_img is not None:
+            ci = cfg_scale if cfg_img is None else cfg_img
+            out = e_uncond + ci * (e_uncond_img - e_uncond) + cfg_scale * (e_cond - e_uncond_img)
+        else:
+            out = e_uncond + cfg_scale * (e_cond - e_uncond)
         if guidance_rescale > 0.0:
             out = rescale_noise_cfg(out, e_cond, guidance_rescale)
     sa = buffers["sqrt_alphas_cumprod"][t]
@@ -131,7 +139,8 @@ def ddim_sample(apply_model: Callable, x_T: torch.Tensor, cond, uncond, S: int, 
                 cfg_scale: float, guidance_rescale: float, buffers: Dict[str, torch.Tensor],
                 method: str = "uniform_trailing",
                 noise_fn: Optional[Callable[[int], torch.Tensor]] = None,
-                step_callback: Optional[Callable] = None):
+                step_callback: Optional[Callable] = None,
+                uncond_img=None, cfg_img: Optional[float] = None):
     """ddim.py:135-203.  `apply_model(x, t_long[b], c)` is the UNet call;
     `noise_fn(i)` supplies the step-i Gaussian draw (the reference takes it from
     the device generator, which cannot be matched across devices, so parity runs
@@ -144,9 +153,10 @@ def ddim_sample(apply_model: Callable, x_T: torch.Tensor, cond, uncond, S: int, 
         ts = torch.full((b,), int(step), dtype=torch.long)
         e_c = apply_model(img, ts, cond)
         e_u = apply_model(img, ts, uncond) if (uncond is not None and cfg_scale != 1.0) else None
+        e_i = apply_model(img, ts, uncond_img) if (e_u is not None and uncond_img is not None) else None
         noise = noise_fn(i) if (noise_fn is not None and eta > 0) else None
         img, pred_x0 = ddim_step(img, e_c, e_u, int(step), index, tab, buffers, cfg_scale,
-                                 guidance_rescale, noise)
+                                 guidance_rescale, noise, e_uncond_img=e_i, cfg_img=cfg_img)
         if step_callback is not None:
             step_callback(i, img, pred_x0)
     return img

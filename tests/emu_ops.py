@@ -177,12 +177,21 @@ class EmuOps:
         x = rows[:, :3].reshape(b, t, h, w_, 3).permute(0, 4, 1, 2, 3)
         return F.conv3d(x, w.reshape(3, 3, 3, 1, 1), bias, padding=(1, 0, 0)).contiguous()
 
+    def video_to_uint8(self, video):
+        v = torch.clamp(video.float(), -1., 1.)
+        v = (v + 1.0) / 2.0
+        return (v * 255).to(torch.uint8).permute(0, 2, 3, 4, 1).contiguous()
+
     def ddim_step(self, x, e_cond, e_uncond, noise, *, cfg_scale, guidance_rescale, sqrt_ac, sqrt_1m_ac,
-                  sqrt_a_prev, dir_coef, sigma, x0_rescale, want_x0=True):
+                  sqrt_a_prev, dir_coef, sigma, x0_rescale, want_x0=True, e_uncond_img=None, cfg_img=None):
         f = lambda v: torch.tensor(v, dtype=torch.float32, device=x.device)
         v = e_cond
         if e_uncond is not None:
-            v = e_uncond + cfg_scale * (e_cond - e_uncond)
+            if e_uncond_img is not None:
+                ci = cfg_scale if cfg_img is None else cfg_img
+                v = e_uncond + ci * (e_uncond_img - e_uncond) + cfg_scale * (e_cond - e_uncond_img)
+            else:
+                v = e_uncond + cfg_scale * (e_cond - e_uncond)
             if guidance_rescale > 0:
                 dims = list(range(1, v.dim()))
                 st = e_cond.double().std(dim=dims, keepdim=True)

@@ -15,6 +15,8 @@ script only calls its public classes and saves input/output tensors:
   unet_tiny.npz      UNetModel forward, 64-channel config, T=4, 8x8 latent
   decoder_tiny.npz   VideoDecoder forward via AutoencoderKL_Dualref.decode, ch=64, T=3
   ddim_tiny.npz      5-step DDIM trajectory (CFG 7.5, rescale 0.7, eta=1, injected noise)
+  ddim_mc_tiny.npz   4-step trajectory of samplers/ddim_multiplecond.py (three-way guidance: text 7.5,
+                     image 3.0, rescale 0.7, eta=1, injected noise) -- SURVEY.md row f3
                      through LatentVisualDiffusion.apply_model, then decode_first_stage
 
 Weights are the deterministic synthetic recipe of tooncrafter_amd/synth.py, keyed
@@ -257,6 +259,34 @@ def main():
                         noises=torch.stack(noises).numpy(), pred_x0=torch.stack(x0s).numpy(),
                         samples=samples.numpy())
     print("ddim_tiny.npz written; final std", float(samples.std()), "finite", bool(torch.isfinite(samples).all()))
+
+    # ---------------------------------------------------------------- tiny multi-condition DDIM trajectory (f3)
+    from lvdm.models.samplers import ddim_multiplecond as ref_mc            # noqa: E402
+    assert ref_mc.__file__.startswith(REF), ref_mc.__file__
+    ref_mc.DDIMSampler.register_buffer = lambda self, n, a: setattr(self, n, a)
+    S = 4
+    ng = torch.Generator().manual_seed(123)
+    noises = [torch.randn(inp["x_T"].shape, generator=ng) for _ in range(S)]
+    it2 = iter(noises)
+    ref_mc.noise_like = lambda shape, device, repeat=False: next(it2)
+    # third condition: text dropped, image tokens kept (what funcs.py would build for img-only guidance)
+    n_text = 77
+    uc_img_ctx = torch.cat([inp["uncond"][:, :n_text], inp["cond"][:, n_text:]], dim=1)
+    uc_img = {"c_crossattn": [uc_img_ctx], "c_concat": [inp["c_concat"]]}
+    sampler = ref_mc.DDIMSampler(model)
+    x0s = []
+    samples, _ = sampler.sample(S=S, conditioning=cond, batch_size=1, shape=(4, T, H, W), verbose=False,
+                                unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=1.0,
+                                cfg_img=3.0, mask=None, x0=None, fs=inp["fs"],
+                                timestep_spacing="uniform_trailing", guidance_rescale=0.7, x_T=inp["x_T"],
+                                unconditional_conditioning_img_nonetext=uc_img,
+                                img_callback=lambda p, i: x0s.append(p.clone()))
+    np.savez_compressed(os.path.join(HERE, "ddim_mc_tiny.npz"), x_T=inp["x_T"].numpy(),
+                        c_concat=inp["c_concat"].numpy(), cond=inp["cond"].numpy(),
+                        uncond=inp["uncond"].numpy(), uncond_img=uc_img_ctx.numpy(), fs=inp["fs"].numpy(),
+                        noises=torch.stack(noises).numpy(), pred_x0=torch.stack(x0s).numpy(),
+                        samples=samples.numpy(), cfg_img=np.float32(3.0))
+    print("ddim_mc_tiny.npz written; final std", float(samples.std()), "finite", bool(torch.isfinite(samples).all()))
 
 
 if __name__ == "__main__":

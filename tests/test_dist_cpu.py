@@ -29,6 +29,19 @@ def _worker(rank, world, port, ret):
     assert (r, w) == (rank, world)
     mine = shard_indices(5, world, rank)
     video = torch.full((1, 3, 4, 8, 8), float(rank + 1)) + torch.arange(8.0)       # rank-specific content
+    # row f4: the writer-side gather moves uint8 frames (converted on every rank before the collective)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from emu_ops import EmuOps
+    from tooncrafter_amd import ops, output
+    ops.set_backend(EmuOps(round_bf16=True))
+    clip = torch.full((1, 3, 2, 4, 4), -1.0 + 0.5 * rank)
+    frames = output.gather_frames(clip, dst=0)
+    if rank == 0:
+        assert [tuple(f.shape) for f in frames] == [(1, 2, 4, 4, 3)] * world and frames[0].dtype == torch.uint8
+        assert [int(f.flatten()[0]) for f in frames] == [int(((-1.0 + 0.5 * r + 1) / 2) * 255) for r in range(world)]
+    else:
+        assert frames is None
     got = gather_clips(video, dst=0)
     if rank == 0:
         ok = len(got) == world and all(torch.equal(g, torch.full((1, 3, 4, 8, 8), float(i + 1)) + torch.arange(8.0))

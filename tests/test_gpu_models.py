@@ -170,6 +170,45 @@ def test_ddim_tiny_trajectory_vs_reference_golden(hip, tiny_sd):
     assert max(errs) < 0.15 and final < 0.15
 
 
+def test_ddim_multicond_tiny_trajectory_vs_reference_golden(hip, tiny_sd):
+    """Row f3 on the GPU: samplers/ddim_multiplecond.py mirror, batch-3 UNet pass + fused three-way step."""
+    from tooncrafter_amd.lvdm import ddim as my_ddim
+    from tooncrafter_amd.lvdm.ddim_multiplecond import DDIMSampler as MultiCondSampler
+    g = load_golden("ddim_mc_tiny.npz")
+    model = _tiny_pipeline(tiny_sd)
+    noises = torch.from_numpy(g["noises"]).to(DEV)
+    dev = lambda k: torch.from_numpy(g[k]).to(DEV)
+    cond = {"c_crossattn": [dev("cond")], "c_concat": [dev("c_concat")]}
+    uc = {"c_crossattn": [dev("uncond")], "c_concat": [dev("c_concat")]}
+    uc_img = {"c_crossattn": [dev("uncond_img")], "c_concat": [dev("c_concat")]}
+
+    def run():
+        it = iter(noises)
+        old = my_ddim.noise_like
+        my_ddim.noise_like = lambda shape, device, repeat=False: next(it)
+        try:
+            x0s = []
+            s = MultiCondSampler(model)
+            out, _ = s.sample(S=4, conditioning=cond, batch_size=1, shape=(4, 4, 8, 8), verbose=False,
+                              unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=1.0,
+                              cfg_img=float(g["cfg_img"]), mask=None, x0=None, fs=dev("fs"),
+                              timestep_spacing="uniform_trailing", guidance_rescale=0.7, x_T=dev("x_T"),
+                              unconditional_conditioning_img_nonetext=uc_img,
+                              img_callback=lambda p, i: x0s.append(p.clone()))
+            return out, x0s
+        finally:
+            my_ddim.noise_like = old
+
+    with torch.no_grad():
+        out, x0s = _with_backend(hip, run)
+    errs = [rel_l2(p.cpu(), torch.from_numpy(g["pred_x0"][i])) for i, p in enumerate(x0s)]
+    final = rel_l2(out.cpu(), torch.from_numpy(g["samples"]))
+    print("multi-cond DDIM-4 tiny trajectory vs reference: pred_x0 rel-L2 per step", [f"{e:.3e}" for e in errs],
+          f"final {final:.3e}")
+    assert torch.isfinite(out).all()
+    assert max(errs) < 0.15 and final < 0.15
+
+
 def test_unet_hipgraph_replay_matches_eager(hip, tiny_unet):
     """The UNet forward is capture-safe (no sync, no host-side allocation outside the caching
     allocator): a hipGraph replay must reproduce the eager result bit for bit."""

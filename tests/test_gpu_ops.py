@@ -266,6 +266,39 @@ def test_ddim_step(hip, emu, cfg, resc, noise):
     check(x0, r0, f"ddim pred_x0 cfg{cfg} resc{resc}", f32=True)
 
 
+@pytest.mark.parametrize("resc,cfg_img", [(0.7, 3.0), (0.0, None)])
+def test_ddim_step_three_way_guidance(hip, emu, resc, cfg_img):
+    """Row f3: e_uncond + cfg_img (e_uncond_img - e_uncond) + s (e_cond - e_uncond_img), then rescale."""
+    shape = (1, 4, 16, 40, 64)
+    x, ec, eu, ei, nz = (rnd(*shape, seed=s, dtype=torch.float32) for s in (60, 61, 62, 63, 64))
+    sc = dict(sqrt_ac=0.6, sqrt_1m_ac=0.8, sqrt_a_prev=0.7, dir_coef=0.5, sigma=0.3, x0_rescale=0.98)
+    xp, x0 = hip.ddim_step(x, ec, eu, nz, cfg_scale=7.5, guidance_rescale=resc, e_uncond_img=ei, cfg_img=cfg_img, **sc)
+    rp, r0 = emu.ddim_step(x, ec, eu, nz, cfg_scale=7.5, guidance_rescale=resc, e_uncond_img=ei, cfg_img=cfg_img, **sc)
+    check(xp, rp, f"ddim3 x_prev resc{resc} cfg_img{cfg_img}", f32=True)
+    check(x0, r0, f"ddim3 pred_x0 resc{resc} cfg_img{cfg_img}", f32=True)
+    # the third pass is really used; with cfg_img == cfg_scale (the reference's default) the formula
+    # collapses algebraically to two-way guidance
+    xp2, _ = hip.ddim_step(x, ec, eu, nz, cfg_scale=7.5, guidance_rescale=resc, **sc)
+    if cfg_img is not None:
+        assert (xp2 - xp).abs().max() > 1e-2
+    else:
+        assert (xp2 - xp).abs().max() < 1e-4
+
+
+def test_video_to_uint8_is_bit_exact(hip, emu):
+    """Row f4: bytes identical to clamp -> (x+1)/2 -> *255 -> uint8 -> permute of inference.py:148-153."""
+    g = torch.Generator().manual_seed(65)
+    v = (torch.randn(2, 3, 5, 24, 40, generator=g) * 0.8)
+    v[0, :, 0, 0, :8] = torch.tensor([-1.0, 1.0, -1.5, 1.5, 0.0, -0.999999, 0.999999, 0.00392156])
+    got = hip.video_to_uint8(v.to(DEV))
+    ref = emu.video_to_uint8(v)                                   # the reference arithmetic on the CPU
+    assert got.dtype == torch.uint8 and tuple(got.shape) == (2, 5, 24, 40, 3)
+    assert torch.equal(got.cpu(), ref)
+    # every multiple of 1/255 round-trips (boundary values of the truncation)
+    lv = (torch.arange(256, dtype=torch.float32) / 255.0 * 2.0 - 1.0).reshape(1, 1, 1, 16, 16).repeat(1, 3, 1, 1, 1)
+    assert torch.equal(hip.video_to_uint8(lv.to(DEV)).cpu(), emu.video_to_uint8(lv))
+
+
 # --------------------------------------------------------------------------- error behaviour
 def test_bad_arguments_raise(hip):
     from tooncrafter_amd._lib import TooncrafterHipError

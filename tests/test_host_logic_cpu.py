@@ -3,6 +3,7 @@ PyTorch (tests/emu_ops.py).  Checks layouts, weight packing, state-dict mapping 
 sampler scalars against the oracle and the reference goldens -- no GPU involved, and
 nothing here measures or ships the emulation."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -120,6 +121,65 @@ def test_ddim_tiny_trajectory_host_logic(tiny_sd, emu_fp32):
     # sampler tables equal the reference's
     assert np.array_equal(sampler.ddim_sigmas, gs["s5_trailing_sigmas"])
     assert np.array_equal(sampler.ddim_alphas_prev, gs["s5_trailing_alphas_prev"])
+
+
+def test_ddim_multicond_trajectory_host_logic(tiny_sd, emu_fp32):
+    """Row f3: the mirror of samplers/ddim_multiplecond.py (three UNet passes as one batch-3 call,
+    three-way guidance inside the fused step) against the reference's 4-step trajectory."""
+    from tooncrafter_amd.lvdm import ddim as my_ddim
+    from tooncrafter_amd.utils import get_obj_from_str, instantiate_from_config
+    g = load_golden("ddim_mc_tiny.npz")
+    model = instantiate_from_config(dict(target="lvdm.models.ddpm3d.LatentVisualDiffusion", params=_tiny_model_cfg())).eval()
+    model.load_state_dict(tiny_sd, strict=False)
+    it = iter(torch.from_numpy(g["noises"]))
+    old = my_ddim.noise_like
+    my_ddim.noise_like = lambda shape, device, repeat=False: next(it)
+    try:
+        sampler = get_obj_from_str("lvdm.models.samplers.ddim_multiplecond.DDIMSampler")(model)
+        t = lambda k: torch.from_numpy(g[k])
+        cond = {"c_crossattn": [t("cond")], "c_concat": [t("c_concat")]}
+        uc = {"c_crossattn": [t("uncond")], "c_concat": [t("c_concat")]}
+        uc_img = {"c_crossattn": [t("uncond_img")], "c_concat": [t("c_concat")]}
+        x0s = []
+        samples, _ = sampler.sample(S=4, conditioning=cond, batch_size=1, shape=(4, 4, 8, 8), verbose=False,
+                                    unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=1.0,
+                                    cfg_img=float(g["cfg_img"]), mask=None, x0=None, fs=t("fs"),
+                                    timestep_spacing="uniform_trailing", guidance_rescale=0.7, x_T=t("x_T"),
+                                    unconditional_conditioning_img_nonetext=uc_img,
+                                    img_callback=lambda p, i: x0s.append(p.clone()))
+    finally:
+        my_ddim.noise_like = old
+    errs = [rel_l2(p, torch.from_numpy(g["pred_x0"][i])) for i, p in enumerate(x0s)]
+    final = rel_l2(samples, torch.from_numpy(g["samples"]))
+    assert max(errs) < 0.15 and final < 0.15, (errs, final)
+    # the third condition is mandatory, like in the reference (KeyError at ddim_multiplecond.py:220)
+    import pytest
+    with pytest.raises(KeyError):
+        sampler.p_sample_ddim(t("x_T"), cond, torch.tensor([999]), index=3, unconditional_guidance_scale=7.5,
+                              unconditional_conditioning=uc, fs=t("fs"))
+
+
+def test_output_path_host_logic(emu_fp32, tmp_path):
+    """Row f4: save_results_seperate mirror -- file naming of inference.py:152, `loop` drops the last frame,
+    bytes equal to the reference's clamp/scale/uint8/permute."""
+    from tooncrafter_amd import output
+    g = torch.Generator().manual_seed(3)
+    samples = torch.randn(2, 3, 4, 8, 12, generator=g)
+    fakedir = str(tmp_path / "samples")
+    seen = []
+    written = output.save_results_seperate(["a prompt"], samples, "clip_007.png", fakedir, fps=8, loop=True,
+                                           writer=lambda path, fr, fps: (seen.append((path, fr.clone(), fps)), path)[1])
+    assert [os.path.basename(w) for w in written] == ["clip_007_sample0.mp4", "clip_007_sample1.mp4"]
+    assert all(os.path.dirname(w).endswith("samples_separate") for w in written)
+    ref = torch.clamp(samples[:, :, :-1].float(), -1., 1.)
+    for i, (path, fr, fps) in enumerate(seen):
+        want = (((ref[i] + 1.0) / 2.0) * 255).to(torch.uint8).permute(1, 2, 3, 0)
+        assert fps == 8 and fr.dtype == torch.uint8 and torch.equal(fr, want)
+    # without a video encoder in the image the default writer leaves an uncompressed .npy
+    out = output.save_results_seperate("p", samples[:1], "x.mp4", fakedir)
+    if out[0].endswith(".npy"):
+        assert np.load(out[0]).shape == (4, 8, 12, 3)
+    assert output.save_results_seperate("p", None, "x.mp4", fakedir) == []
 
 
 def test_step_scalars_first_step_is_finite():

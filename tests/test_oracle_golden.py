@@ -92,6 +92,29 @@ def test_ddim_tiny_trajectory_matches_reference(tiny_sd):
     assert rel_l2(out, torch.from_numpy(g["samples"])) < 1e-4
 
 
+def test_ddim_multicond_tiny_trajectory_matches_reference(tiny_sd):
+    """Row f3: three-way guidance of samplers/ddim_multiplecond.py (text 7.5, image 3.0, rescale 0.7)."""
+    g = load_golden("ddim_mc_tiny.npz")
+    sd = sub_state_dict(tiny_sd, "model.diffusion_model.")
+    bufs = osamp.make_schedule_buffers()
+    c_concat = torch.from_numpy(g["c_concat"])
+    fs = torch.from_numpy(g["fs"])
+
+    def apply_model(x, t, ctx):
+        return ounet.unet_forward(sd, TINY_UNET_CFG, torch.cat([x, c_concat], dim=1), t, ctx, fs)
+
+    noises = torch.from_numpy(g["noises"])
+    x0s = []
+    out = osamp.ddim_sample(apply_model, torch.from_numpy(g["x_T"]), torch.from_numpy(g["cond"]),
+                            torch.from_numpy(g["uncond"]), S=4, eta=1.0, cfg_scale=7.5, guidance_rescale=0.7,
+                            buffers=bufs, noise_fn=lambda i: noises[i],
+                            step_callback=lambda i, img, p: x0s.append(p),
+                            uncond_img=torch.from_numpy(g["uncond_img"]), cfg_img=float(g["cfg_img"]))
+    for i, p in enumerate(x0s):
+        assert rel_l2(p, torch.from_numpy(g["pred_x0"][i])) < 1e-4, i
+    assert rel_l2(out, torch.from_numpy(g["samples"])) < 1e-4
+
+
 def test_encoder_tiny_matches_reference(tiny_sd):
     from oracle import encoder as oenc
     g = load_golden("encoder_tiny.npz")

@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libtooncrafter_hip.so")
 
-TC_ABI_VERSION = 2
+TC_ABI_VERSION = 3
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_GEGLU = 0, 1, 2, 3
 GATHER_LINEAR, GATHER_CONV3x3, GATHER_CONVT3 = 0, 1, 2
 
@@ -54,6 +54,7 @@ class TcDdimParams(C.Structure):
         ("cfg_scale", C.c_float), ("guidance_rescale", C.c_float),
         ("sqrt_ac", C.c_float), ("sqrt_1m_ac", C.c_float), ("sqrt_a_prev", C.c_float),
         ("dir_coef", C.c_float), ("sigma", C.c_float), ("x0_rescale", C.c_float),
+        ("e_uncond_img", C.c_void_p), ("cfg_img", C.c_float),
     ]
 
 
@@ -78,6 +79,7 @@ SYMBOLS = {
     "tc_silu_f32_to_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "tc_time_mix3": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                C.c_int32, C.c_void_p]),
+    "tc_video_to_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "tc_ddim_workspace": (C.c_int64, [C.c_int32]),
     "tc_ddim_step": (C.c_int, [C.POINTER(TcDdimParams), C.c_void_p, C.c_int64, C.c_void_p]),
     "tc_abi_version": (C.c_int, []),

@@ -122,16 +122,21 @@ __global__ void time_mix3_kernel(const float* __restrict__ rows, int ld, const f
 constexpr int DDIM_PARTS = 64;
 
 __device__ __forceinline__ float cfg_combine(float ec, float eu, float scale) { return eu + scale * (ec - eu); }
+// three-way guidance, evaluated left to right like ddim_multiplecond.py:236
+__device__ __forceinline__ float cfg_combine3(float ec, float eu, float ei, float scale, float scale_img) {
+  return eu + scale_img * (ei - eu) + scale * (ec - ei);
+}
 
 __global__ __launch_bounds__(256) void ddim_stats_kernel(TcDdimParams p, double* __restrict__ part) {
   __shared__ double red[4][4];
   const int b = blockIdx.y;
   const float* ec = p.e_cond + (int64_t)b * p.n;
   const float* eu = p.e_uncond + (int64_t)b * p.n;
+  const float* ei = p.e_uncond_img ? p.e_uncond_img + (int64_t)b * p.n : nullptr;
   double s[4] = {0, 0, 0, 0};
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.n; i += (int64_t)DDIM_PARTS * 256) {
     const float c = ec[i];
-    const float g = cfg_combine(c, eu[i], p.cfg_scale);
+    const float g = ei ? cfg_combine3(c, eu[i], ei[i], p.cfg_scale, p.cfg_img) : cfg_combine(c, eu[i], p.cfg_scale);
     s[0] += c; s[1] += (double)c * c; s[2] += g; s[3] += (double)g * g;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -175,7 +180,8 @@ __global__ __launch_bounds__(256) void ddim_apply_kernel(TcDdimParams p, const d
     const float x = p.x[base + i];
     float v = p.e_cond[base + i];
     if (cfg) {
-      v = cfg_combine(v, p.e_uncond[base + i], p.cfg_scale);
+      v = p.e_uncond_img ? cfg_combine3(v, p.e_uncond[base + i], p.e_uncond_img[base + i], p.cfg_scale, p.cfg_img)
+                         : cfg_combine(v, p.e_uncond[base + i], p.cfg_scale);
       if (resc) v = p.guidance_rescale * (v * factor) + (1.f - p.guidance_rescale) * v;
     }
     const float e_t = p.sqrt_ac * v + p.sqrt_1m_ac * x;
@@ -185,6 +191,23 @@ __global__ __launch_bounds__(256) void ddim_apply_kernel(TcDdimParams p, const d
     if (p.noise) xp += p.sigma * p.noise[base + i];
     p.x_prev[base + i] = xp;
     if (p.pred_x0) p.pred_x0[base + i] = x0;
+  }
+}
+
+// (b, 3, t, hw) fp32 -> (b, t, hw, 3) uint8: one thread per pixel reads its three channel planes
+// (coalesced per plane) and writes 3 consecutive bytes.
+__global__ __launch_bounds__(256) void video_to_u8_kernel(const float* __restrict__ x, uint8_t* __restrict__ out,
+                                                          int t, int64_t hw, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t frame = i / hw, pix = i - frame * hw;         // frame = b*t + tt
+    const int64_t b = frame / t, tt = frame - b * t;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float v = x[((b * 3 + c) * t + tt) * hw + pix];
+      v = fminf(fmaxf(v, -1.f), 1.f);
+      v = (v + 1.0f) / 2.0f;
+      out[i * 3 + c] = (uint8_t)(v * 255.f);                    // fp32 -> u8 truncates, like Tensor.to(uint8)
+    }
   }
 }
 
@@ -262,12 +285,22 @@ extern "C" int tc_time_mix3(const float* rows, int32_t ld, const float* w, const
   return TC_OK;
 }
 
+extern "C" int tc_video_to_u8(const float* x, uint8_t* out, int32_t b, int32_t t, int32_t hw, void* stream) {
+  if (!x || !out || b <= 0 || t <= 0 || hw <= 0) return TC_EINVAL;
+  const int64_t total = (int64_t)b * t * hw;
+  hipLaunchKernelGGL(video_to_u8_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, out, t, (int64_t)hw, total);
+  TC_LAUNCH_CHECK();
+  return TC_OK;
+}
+
 extern "C" int64_t tc_ddim_workspace(int32_t b) { return b > 0 ? (int64_t)b * DDIM_PARTS * 4 * sizeof(double) : 0; }
 
 extern "C" int tc_ddim_step(const TcDdimParams* pp, void* workspace, int64_t workspace_bytes, void* stream) {
   if (!pp) return TC_EINVAL;
   const TcDdimParams& p = *pp;
   if (!p.x || !p.e_cond || !p.x_prev || p.b <= 0 || p.n <= 1) return TC_EINVAL;
+  if (p.e_uncond_img && !p.e_uncond) return TC_EINVAL;
   if (!workspace || workspace_bytes < tc_ddim_workspace(p.b)) return TC_EWORKSPACE;
   if (p.b > 65535) return TC_ESHAPE;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -208,23 +208,30 @@ class LatentDiffusion(DDPM):
     def apply_model_cfg(self, x_noisy, t, cond, uncond, **kwargs):
         """Conditional and unconditional passes as ONE batch-2B UNet call.  Exact: every
         normalisation and attention in the UNet is per sample."""
+        return tuple(self.apply_model_multi(x_noisy, t, [cond, uncond], **kwargs))
+
+    def apply_model_multi(self, x_noisy, t, conds, **kwargs):
+        """The UNet passes of one guided step -- 2 for ddim.py:226-233, 3 for
+        ddim_multiplecond.py:226-236 -- as ONE batch-(n B) call; returns one output per entry of
+        `conds`, in order."""
+        n = len(conds)
         if self.model.conditioning_key != 'hybrid':
-            return self.apply_model(x_noisy, t, cond, **kwargs), self.apply_model(x_noisy, t, uncond, **kwargs)
+            return [self.apply_model(x_noisy, t, c, **kwargs) for c in conds]
         b = x_noisy.shape[0]
         fs = kwargs.get("fs")
-        cond_t = [*cond["c_crossattn"], *cond["c_concat"], *uncond["c_crossattn"], *uncond["c_concat"]]
-        sig = tuple((c.data_ptr(), c._version, tuple(c.shape)) for c in cond_t) + (
+        cond_t = [tns for c in conds for tns in (*c["c_crossattn"], *c["c_concat"])]
+        sig = (n,) + tuple((c.data_ptr(), c._version, tuple(c.shape)) for c in cond_t) + (
             None if fs is None else (fs.data_ptr(), fs._version), tuple(x_noisy.shape), x_noisy.device)
         st = self._cfg_state
         unet = self.model.diffusion_model
         if st is None or st["sig"] != sig:
-            # conditioning changed (new clip): (re)fill the static batch-2B inputs; same-shape buffers are
+            # conditioning changed (new clip): (re)fill the static batch-nB inputs; same-shape buffers are
             # reused so that a captured graph stays valid
-            cat = lambda key: torch.cat([torch.cat(cond[key], 1), torch.cat(uncond[key], 1)], dim=0)
+            cat = lambda key: torch.cat([torch.cat(c[key], 1) for c in conds], dim=0)
             ctx2, cc2 = cat("c_crossattn"), cat("c_concat").to(torch.float32)
-            fs2 = None if fs is None else torch.cat([fs, fs], dim=0)
+            fs2 = None if fs is None else torch.cat([fs] * n, dim=0)
             if st is not None and st["ctx2"].shape == ctx2.shape and st["x2"].shape[1:] == x_noisy.shape[1:] \
-                    and st["x2"].shape[0] == 2 * b and st["x2"].device == x_noisy.device \
+                    and st["x2"].shape[0] == n * b and st["x2"].device == x_noisy.device \
                     and (st["fs2"] is None) == (fs2 is None):
                 st["ctx2"].copy_(ctx2)
                 st["cc2"].copy_(cc2)
@@ -233,14 +240,13 @@ class LatentDiffusion(DDPM):
             else:
                 st = self._cfg_state = dict(
                     ctx2=ctx2.contiguous(), cc2=cc2.contiguous(), fs2=fs2,
-                    x2=torch.empty((2 * b, *x_noisy.shape[1:]), dtype=torch.float32, device=x_noisy.device),
-                    ts2=torch.empty((2 * b,), dtype=torch.long, device=x_noisy.device), graph=None, calls=0)
+                    x2=torch.empty((n * b, *x_noisy.shape[1:]), dtype=torch.float32, device=x_noisy.device),
+                    ts2=torch.empty((n * b,), dtype=torch.long, device=x_noisy.device), graph=None, calls=0)
             st["sig"] = sig
             unet.context_cache(st["ctx2"], x_noisy.shape[2])          # project K/V now (in place if cached)
-        st["x2"][:b].copy_(x_noisy)
-        st["x2"][b:].copy_(x_noisy)
-        st["ts2"][:b].copy_(t)
-        st["ts2"][b:].copy_(t)
+        for k in range(n):
+            st["x2"][k * b:(k + 1) * b].copy_(x_noisy)
+            st["ts2"][k * b:(k + 1) * b].copy_(t)
 
         def fwd():
             return unet(None, st["ts2"], context=st["ctx2"], fs=st["fs2"], x_parts=[st["x2"], st["cc2"]])
@@ -259,7 +265,7 @@ class LatentDiffusion(DDPM):
         else:
             out = fwd()
         st["calls"] += 1
-        return out[:b], out[b:]
+        return [out[k * b:(k + 1) * b] for k in range(n)]
 
     @torch.no_grad()
     def decode_first_stage(self, z, **kwargs):

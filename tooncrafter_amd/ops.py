@@ -265,9 +265,22 @@ class HipOps:
                                          out.data_ptr(), b, t, h * w_, _stream()), "tc_time_mix3")
         return out
 
+    def video_to_uint8(self, video):
+        """(b, 3, t, h, w) fp32 in [-1, 1] -> (b, t, h, w, 3) uint8: clamp, (x+1)/2*255, truncate, permute
+        (scripts/evaluation/inference.py:148-153), on the device."""
+        if video.dtype != torch.float32 or video.dim() != 5 or video.shape[1] != 3 or not video.is_cuda:
+            raise ValueError("video_to_uint8: fp32 CUDA (b, 3, t, h, w)")
+        video = video.contiguous()
+        b, _, t, h, w = video.shape
+        out = torch.empty((b, t, h, w, 3), dtype=torch.uint8, device=video.device)
+        _lib.check(self.lib.tc_video_to_u8(video.data_ptr(), out.data_ptr(), b, t, h * w, _stream()), "tc_video_to_u8")
+        return out
+
     def ddim_step(self, x, e_cond, e_uncond, noise, *, cfg_scale, guidance_rescale, sqrt_ac, sqrt_1m_ac,
-                  sqrt_a_prev, dir_coef, sigma, x0_rescale, want_x0=True):
-        for tns in (x, e_cond, e_uncond, noise):
+                  sqrt_a_prev, dir_coef, sigma, x0_rescale, want_x0=True, e_uncond_img=None, cfg_img=None):
+        """One fused DDIM update.  With `e_uncond_img` the guidance is the three-way form of
+        ddim_multiplecond.py:236 (cfg_img defaults to cfg_scale like the reference)."""
+        for tns in (x, e_cond, e_uncond, noise, e_uncond_img):
             if tns is not None and (tns.dtype != torch.float32 or not tns.is_contiguous() or not tns.is_cuda):
                 raise ValueError("ddim_step: contiguous fp32 CUDA tensors")
         b = x.shape[0]
@@ -281,6 +294,8 @@ class HipOps:
         p.cfg_scale, p.guidance_rescale = float(cfg_scale), float(guidance_rescale)
         p.sqrt_ac, p.sqrt_1m_ac, p.sqrt_a_prev = float(sqrt_ac), float(sqrt_1m_ac), float(sqrt_a_prev)
         p.dir_coef, p.sigma, p.x0_rescale = float(dir_coef), float(sigma), float(x0_rescale)
+        p.e_uncond_img = _ptr(e_uncond_img)
+        p.cfg_img = float(cfg_scale if cfg_img is None else cfg_img)
         nbytes = self.lib.tc_ddim_workspace(b)
         ws = self._workspace(nbytes, x.device)
         _lib.check(self.lib.tc_ddim_step(C.byref(p), ws.data_ptr(), nbytes, _stream()), "tc_ddim_step")

@@ -13,6 +13,7 @@ MODULE_ALIASES = {
     "lvdm.models.autoencoder_dualref": "tooncrafter_amd.lvdm.autoencoder_dualref",
     "lvdm.models.utils_diffusion": "tooncrafter_amd.lvdm.utils_diffusion",
     "lvdm.models.samplers.ddim": "tooncrafter_amd.lvdm.ddim",
+    "lvdm.models.samplers.ddim_multiplecond": "tooncrafter_amd.lvdm.ddim_multiplecond",
     "lvdm.modules.attention": "tooncrafter_amd.lvdm.attention",
     "lvdm.modules.networks.openaimodel3d": "tooncrafter_amd.lvdm.openaimodel3d",
     "lvdm.modules.encoders.condition": "tooncrafter_amd.lvdm.condition",
