@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TC_ABI_VERSION 3
+#define TC_ABI_VERSION 4
 
 enum {
   TC_OK = 0,
@@ -80,6 +80,11 @@ typedef struct TcGemmParams {
   /* batching (blockIdx.z): element strides, 0 = shared */
   int32_t batch;
   int64_t stride_a, stride_w, stride_c;
+  /* ABI 4 -- optional scratch for split-K: low-resolution layers (few output tiles, long K) are cut along K
+   * over several blocks per tile, fp32 partial tiles go here and a second kernel sums them in a fixed order
+   * and applies the epilogue (bit-reproducible).  NULL / too small = never split. */
+  void* workspace;
+  int64_t workspace_bytes;
 } TcGemmParams;
 
 /* C = epilogue(gather(A) * W^T), bf16 MFMA, fp32 accumulate.
@@ -89,6 +94,8 @@ typedef struct TcGemmParams {
  * autoencoder_dualref.py:601-605,641-648), F.interpolate nearest x2 (openaimodel3d.py:98-106),
  * GEGLU (attention.py:420-422) and the residual/embedding adds around them. */
 int tc_gemm_bf16(const TcGemmParams* p, void* stream);
+/* bytes of TcGemmParams.workspace this problem would use (0: it is not a split-K candidate) */
+int64_t tc_gemm_workspace(const TcGemmParams* p);
 
 typedef struct TcAttnParams {
   const tc_bf16* q; const tc_bf16* k; const tc_bf16* v; tc_bf16* o;

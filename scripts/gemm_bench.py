@@ -70,6 +70,27 @@ if __name__ == "__main__":
     conv(32, 10, 16, 1280, 1280, "L2 tconv", t3=True)
     conv(16, 80, 128, 512, 512, "dec L2")
     conv(16, 320, 512, 128, 128, "dec L0")
+    if "--more" in sys.argv:     # further shapes of the UNet (B=2) and decoder for the tile sweep
+        lin(20480, 1920, 640, tag="L1 qkv")
+        lin(5120, 3840, 1280, tag="L2 qkv")
+        lin(1280, 1280, 1280, res=True, tag="L3 proj")
+        lin(1280, 3840, 1280, tag="L3 qkv")
+        lin(1280, 10240, 1280, act=ACT_GEGLU, tag="L3 geglu")
+        lin(1280, 1280, 5120, res=True, tag="L3 ff2")
+        conv(32, 40, 64, 640, 320, "L0 res 640in")
+        conv(32, 40, 64, 960, 320, "L0 res 960in")
+        conv(32, 20, 32, 1280, 640, "L1 res 1280in")
+        conv(32, 20, 32, 320, 640, "L1 res 320in")
+        conv(32, 10, 16, 2560, 1280, "L2 res 2560in")
+        conv(32, 5, 8, 2560, 1280, "L3 res 2560in")
+        conv(32, 20, 32, 640, 640, "L1 tconv", t3=True)
+        conv(32, 5, 8, 1280, 1280, "L3 tconv", t3=True)
+        conv(16, 40, 64, 512, 512, "dec L3")
+        conv(16, 160, 256, 256, 256, "dec L1")
+        conv(16, 160, 256, 512, 256, "dec L1 512in")
+        conv(16, 320, 512, 256, 128, "dec L0 256in")
+    if "--no-attn" in sys.argv:
+        sys.exit(0)
 
 
 def attn(batch, heads, lq, lk, kv_bdiv=1, tag=""):

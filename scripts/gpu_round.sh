@@ -19,7 +19,8 @@ for s in $STAGES; do
     bench)  timeout 900 python bench.py --steps 1 --warmup 1 --ddim-steps 4 --no-cpu-baseline > $OUT/bench_short.log 2>&1 ;;
     benchfull) timeout 1500 python bench.py --steps 2 --warmup 1 > $OUT/bench_full.log 2>&1 ;;
     gemmbench) timeout 600 python scripts/gemm_bench.py > $OUT/gemm_bench.log 2>&1 ;;
-    benchab) (for g in 1 0 1 0; do echo "== AB=$g"; TC_AB=$g timeout 600 python bench.py --steps 1 --warmup 1 --ddim-steps 6 --no-cpu-baseline; done) > $OUT/bench_ab.log 2>&1 ;;
+    benchab) (for g in "TC_NOOP=1" "${AB_ENV:-TC_NOOP=2}" "TC_NOOP=1" "${AB_ENV:-TC_NOOP=2}"; do echo "== $g"; env $g timeout 600 python bench.py --steps 1 --warmup 1 --ddim-steps 6 --no-cpu-baseline; done) > $OUT/bench_ab.log 2>&1 ;;
+    tilesweep) timeout 900 bash scripts/gemm_tile_sweep.sh > $OUT/tile_sweep.log 2>&1 ;;
     prof)   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o prof -- python $OLDPWD/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OLDPWD/$OUT/prof.log 2>&1) ;;
     *) echo "unknown stage $s" ;;
   esac

@@ -266,6 +266,33 @@ def test_ddim_step(hip, emu, cfg, resc, noise):
     check(x0, r0, f"ddim pred_x0 cfg{cfg} resc{resc}", f32=True)
 
 
+def test_gemm_split_k_low_resolution_layers(hip, emu):
+    """The lowest-resolution UNet layers (M = B*T*5*8 = 1280 rows) run split-K: partial fp32 tiles in the
+    workspace, fixed-order reduction + epilogue in a second kernel.  Parity with every fused term, and
+    bit-identical reruns."""
+    from tooncrafter_amd._lib import TcGemmParams
+    import ctypes as C
+    m, n, cin = 1280, 1280, 1280
+    x = rnd(m, cin, seed=70)
+    w = rnd(n, 9 * cin, seed=71, scale=(9 * cin) ** -0.5)
+    bias, rb = rnd(n, seed=72, dtype=torch.float32), rnd(32, n, seed=73, dtype=torch.float32)
+    res = rnd(m, n, seed=74)
+    geom = dict(kind="3x3", frames=32, cin=cin, h_in=5, w_in=8, h_out=5, w_out=8, stride=1, upsample=False)
+    p = TcGemmParams(); p.m, p.n, p.k, p.batch, p.act = m, n, 9 * cin, 1, 0
+    assert hip.lib.tc_gemm_workspace(C.byref(p)) == 5 * m * n * 4            # 100 tiles -> 5 K-slices
+    got = hip.gemm(x, w, bias, conv=geom, row_bias=rb, row_div=40, residual=res, act=ACT_SILU)
+    ref = emu.gemm(x, w, bias, conv=geom, row_bias=rb, row_div=40, residual=res, act=ACT_SILU)
+    check(got, ref, "split-K conv3x3 L3 (bias + row_bias + silu + residual)")
+    assert torch.equal(got, hip.gemm(x, w, bias, conv=geom, row_bias=rb, row_div=40, residual=res, act=ACT_SILU))
+    # linear with a ragged K tail and fp32 output (K just past the split threshold)
+    a2, w2 = rnd(1000, 8200, seed=75), rnd(264, 8200, seed=76, scale=8200 ** -0.5)
+    p.m, p.n, p.k = 1000, 264, 8200
+    assert hip.lib.tc_gemm_workspace(C.byref(p)) > 0
+    check(hip.gemm(a2, w2, out_f32=True), emu.gemm(a2, w2, out_f32=True), "split-K linear ragged f32", f32=True)
+    p.k = 5120
+    assert hip.lib.tc_gemm_workspace(C.byref(p)) == 0                         # short K: 64x64 tiles instead
+
+
 @pytest.mark.parametrize("resc,cfg_img", [(0.7, 3.0), (0.0, None)])
 def test_ddim_step_three_way_guidance(hip, emu, resc, cfg_img):
     """Row f3: e_uncond + cfg_img (e_uncond_img - e_uncond) + s (e_cond - e_uncond_img), then rescale."""

@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libtooncrafter_hip.so")
 
-TC_ABI_VERSION = 3
+TC_ABI_VERSION = 4
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_GEGLU = 0, 1, 2, 3
 GATHER_LINEAR, GATHER_CONV3x3, GATHER_CONVT3 = 0, 1, 2
 
@@ -33,6 +33,7 @@ class TcGemmParams(C.Structure):
         ("stride", C.c_int32), ("upsample", C.c_int32), ("pad", C.c_int32),
         ("batch", C.c_int32),
         ("stride_a", C.c_int64), ("stride_w", C.c_int64), ("stride_c", C.c_int64),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 
@@ -61,6 +62,7 @@ class TcDdimParams(C.Structure):
 # name -> (restype, argtypes): every symbol include/tooncrafter_hip.h declares
 SYMBOLS = {
     "tc_gemm_bf16": (C.c_int, [C.POINTER(TcGemmParams), C.c_void_p]),
+    "tc_gemm_workspace": (C.c_int64, [C.POINTER(TcGemmParams)]),
     "tc_attn_d64": (C.c_int, [C.POINTER(TcAttnParams), C.c_void_p]),
     "tc_attn_temporal": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_float, C.c_void_p]),

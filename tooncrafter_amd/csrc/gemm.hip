@@ -160,7 +160,18 @@ __device__ __forceinline__ void epilogue_tail(const TcGemmParams& p, const float
 }
 
 template <int GATHER, int TM, int TN>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams p) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams pin, const int splits) {
+  // split-K (blockIdx.y = slice of the K loop): the block emits its raw fp32 partial tile into the
+  // workspace -- the plain epilogue with every fused term switched off -- and splitk_reduce_kernel
+  // finishes the job
+  TcGemmParams p = pin;
+  if (splits > 1) {
+    p.c = reinterpret_cast<float*>(pin.workspace) + (int64_t)blockIdx.y * pin.m * pin.n;
+    p.ldc = pin.n;
+    p.out_f32 = 1;
+    p.bias = nullptr; p.row_bias = nullptr; p.residual = nullptr;
+    p.act = TC_ACT_NONE; p.alpha = 1.f; p.out_scale = 1.f;
+  }
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int STAGE_BYTES = (BM + BN) * BK * 2;                       // 32 KiB per stage at 128x128
   constexpr int EPI_BYTES = BM * BN * 4;
@@ -275,15 +286,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams p) {
   // LDS-DMA data is visible to a ds_read only after the issuing wave's vmcnt wait AND a barrier the
   // reader has passed (MI355X_MICROARCH.md); the same barrier also retires the reads of the stage the
   // next iteration overwrites.
-  const int nk = (p.k + BK - 1) / BK;
-  load_tile(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int kb = 0; kb < nk; ++kb) {
-    if (kb + 1 < nk) load_tile(kb + 1, (kb + 1) & 1);
-    compute(kb & 1);
+  const int nk_all = (p.k + BK - 1) / BK;
+  const int per = (nk_all + splits - 1) / splits;
+  const int kb0 = blockIdx.y * per;
+  const int nk = min(nk_all, kb0 + per);          // this block runs K-steps [kb0, nk); possibly none
+  if (kb0 < nk) {
+    load_tile(kb0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    for (int kb = kb0; kb < nk; ++kb) {
+      if (kb + 1 < nk) load_tile(kb + 1, (kb + 1 - kb0) & 1);
+      compute((kb - kb0) & 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: accumulators -> LDS fp32 [BM][BN] -> row vectors
@@ -311,7 +327,80 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams p) {
   else epilogue_fast<false, BM, BN, false>(p, cs, tid, tile_m, tile_n, bz);
 }
 
+// Sum the split-K partial tiles (fixed order: bit-reproducible) and apply the epilogue of `p`:
+// one thread per 8 consecutive output columns.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const TcGemmParams p, const int splits) {
+  const int vpr = p.n >> 3;
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (v >= (int64_t)p.m * vpr) return;
+  const int m = (int)(v / vpr), n0 = (int)(v - (int64_t)m * vpr) * 8;
+  const float* ws = reinterpret_cast<const float*>(p.workspace) + (int64_t)m * p.n + n0;
+  float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < splits; ++s) {
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(ws + (int64_t)s * p.m * p.n);
+    const f32x4 hi = *reinterpret_cast<const f32x4*>(ws + (int64_t)s * p.m * p.n + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { x[e] += lo[e]; x[4 + e] += hi[e]; }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float t = x[e] * p.alpha;
+    if (p.bias) t += p.bias[n0 + e];
+    if (p.row_bias) t += p.row_bias[(int64_t)(m / p.row_div) * p.ldrb + n0 + e];
+    x[e] = apply_act(t, p.act) * p.out_scale;
+  }
+  if (p.residual) {
+    float rf[8];
+    unpack8(*reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.residual) + (int64_t)m * p.ldr + n0), rf);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] += rf[e];
+  }
+  if (p.out_f32) {
+    float* op = reinterpret_cast<float*>(p.c) + (int64_t)m * p.ldc + n0;
+    *reinterpret_cast<f32x4*>(op) = f32x4{x[0], x[1], x[2], x[3]};
+    *reinterpret_cast<f32x4*>(op + 4) = f32x4{x[4], x[5], x[6], x[7]};
+  } else {
+    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.c) + (int64_t)m * p.ldc + n0) = pack8(x);
+  }
+}
+
 }  // namespace
+
+// Split-K factor (1 = no split).  Candidates: one problem (no batching), vector epilogue, no GEGLU, so few
+// 128x128 tiles that most of the 512 block slots (2 per CU) would idle, and a K long enough to pay for
+// the partial tiles and the reduction pass (~12 us): measured on the M = 1280 layers
+// (profiles/r01_v6_gemm_splitk.txt) the 3x3 convolutions (K = 11520 / 23040) gain 1.28x / 1.51x over
+// their 64x64-tile launch, while K <= 5120 (linear, temporal conv) loses -- those keep the 64x64 tiles.
+// TC_GEMM_SPLITK=n forces n (tuning), 0 disables.
+static int tc_gemm_splits(const TcGemmParams& p) {
+  static const int force = [] { const char* e = getenv("TC_GEMM_SPLITK"); return e ? atoi(e) : -1; }();
+  const int batch = p.batch > 0 ? p.batch : 1;
+  if (force == 0 || batch != 1 || p.act == TC_ACT_GEGLU || (p.n & 7) != 0) return 1;
+  const int nk = (p.k + BK - 1) / BK;
+  const int64_t tiles = (int64_t)((p.n + 127) / 128) * ((p.m + 127) / 128);
+  if (tiles >= 200 || (force < 0 && nk < 128)) return 1;
+  int s = force > 0 ? force : (int)(512 / tiles);
+  if (s > 8) s = 8;
+  if (s > nk / 8) s = nk / 8;
+  return s < 2 ? 1 : s;
+}
+
+extern "C" int64_t tc_gemm_workspace(const TcGemmParams* p) {
+  if (!p || p->m <= 0 || p->n <= 0 || p->k <= 0) return 0;
+  const int s = tc_gemm_splits(*p);
+  return s > 1 ? (int64_t)s * p->m * p->n * (int64_t)sizeof(float) : 0;
+}
+
+// Tile family for the 4-wave kernel: (64 tm) x (64 tn).  The sweep (profiles/r01_v6_gemm_tile_sweep.txt)
+// has 128x128 ahead on every UNet/decoder shape -- 128x64 and 64x128 lose 5-45 % to their higher LDS/L1
+// traffic per FLOP even where they would fill the CUs more evenly -- except the lowest-resolution layers
+// (M = 1280 rows), whose 100 128-tiles leave most of the 256 CUs idle: those take 64x64 (+32-37 %).
+static void tc_gemm_pick_tile(int m, int n, int batch, bool geglu, int* tm, int* tn) {
+  const int64_t big_tiles = (int64_t)((n + 127) / 128) * ((m + 127) / 128) * batch;
+  const bool small = !geglu && big_tiles < 384;
+  *tm = small ? 1 : 2;
+  *tn = small ? 1 : 2;
+}
 
 extern "C" int tc_gemm_bf16(const TcGemmParams* pp, void* stream) {
   if (!pp) return TC_EINVAL;
@@ -357,29 +446,42 @@ extern "C" int tc_gemm_bf16(const TcGemmParams* pp, void* stream) {
   }
   if (!tc_gemm_offsets_fit(p)) return TC_ESHAPE;          // buffer-load offsets are 31-bit
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  // TC_GEMM_TILE = wide | big | small forces one tile family (tuning / A-B runs); default: heuristic
+  // TC_GEMM_TILE = wide | 22 | 21 | 12 | 11 forces one tile family (tuning / A-B runs); default: heuristic
   static const int force = [] {
     const char* e = getenv("TC_GEMM_TILE");
     if (!e) return 0;
-    return e[0] == 'w' ? 1 : e[0] == 'b' ? 2 : e[0] == 's' ? 3 : 0;
+    if (e[0] == 'w') return 1;
+    if (e[0] == 'b') return 22;
+    if (e[0] == 's') return 11;
+    const int v = atoi(e);
+    return (v == 22 || v == 21 || v == 12 || v == 11) ? v : 0;
   }();
   if (force <= 1 && tc_gemm_wide_try(p, batch, s, force == 1)) {       // big-M layers: 256-row tiles
     TC_LAUNCH_CHECK();
     return TC_OK;
   }
-  // otherwise 128x128, or 64x64 when that would leave most of the 256 CUs idle (low-resolution layers)
-  const int64_t big_tiles = (int64_t)((p.n + 127) / 128) * ((p.m + 127) / 128) * batch;
-  const bool small = force == 3 ? !geglu : force == 2 ? false : (!geglu && big_tiles < 384);
-  const int bm = small ? 64 : 128, bn = small ? 64 : 128;
+  int tm = 2, tn = 2;
+  int splits = (p.workspace && force == 0) ? tc_gemm_splits(p) : 1;
+  if (splits > 1 && p.workspace_bytes < (int64_t)splits * p.m * p.n * (int64_t)sizeof(float)) splits = 1;
+  if (splits > 1 && !tc_aligned16(p.workspace)) return TC_EALIGN;
+  if (force > 1) {
+    tm = force / 10;
+    tn = geglu ? 2 : force % 10;
+  } else if (splits == 1) {
+    tc_gemm_pick_tile(p.m, p.n, batch, geglu, &tm, &tn);
+  }
+  const int bm = 64 * tm, bn = 64 * tn;
   const int tiles_n = (p.n + bn - 1) / bn;
   const int tiles_m = (p.m + bm - 1) / bm;
   const int64_t nblk = (int64_t)tiles_n * 8 * ((tiles_m + 7) / 8);
   if (nblk > 0x7fffffffLL || batch > 65535) return TC_ESHAPE;
-  dim3 grid((unsigned)nblk, 1, (unsigned)batch), block(256);
-#define TC_LAUNCH_GEMM(G)                                                              \
-  do {                                                                                 \
-    if (small) hipLaunchKernelGGL((gemm_kernel<G, 1, 1>), grid, block, 0, s, p);       \
-    else hipLaunchKernelGGL((gemm_kernel<G, 2, 2>), grid, block, 0, s, p);             \
+  dim3 grid((unsigned)nblk, (unsigned)splits, (unsigned)batch), block(256);
+#define TC_LAUNCH_GEMM(G)                                                                           \
+  do {                                                                                              \
+    if (tm == 2 && tn == 2) hipLaunchKernelGGL((gemm_kernel<G, 2, 2>), grid, block, 0, s, p, splits);      \
+    else if (tm == 2) hipLaunchKernelGGL((gemm_kernel<G, 2, 1>), grid, block, 0, s, p, splits);            \
+    else if (tn == 2) hipLaunchKernelGGL((gemm_kernel<G, 1, 2>), grid, block, 0, s, p, splits);            \
+    else hipLaunchKernelGGL((gemm_kernel<G, 1, 1>), grid, block, 0, s, p, splits);                         \
   } while (0)
   switch (p.gather) {
     case TC_GATHER_LINEAR: TC_LAUNCH_GEMM(TC_GATHER_LINEAR); break;
@@ -388,5 +490,10 @@ extern "C" int tc_gemm_bf16(const TcGemmParams* pp, void* stream) {
   }
 #undef TC_LAUNCH_GEMM
   TC_LAUNCH_CHECK();
+  if (splits > 1) {
+    const int64_t vecs = (int64_t)p.m * (p.n >> 3);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((vecs + 255) / 256)), dim3(256), 0, s, p, splits);
+    TC_LAUNCH_CHECK();
+  }
   return TC_OK;
 }

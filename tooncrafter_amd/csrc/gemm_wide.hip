@@ -302,10 +302,17 @@ int tc_gemm_wide_try(const TcGemmParams& p, int batch, hipStream_t s, bool force
   const int tiles_n = (p.n + bn - 1) / bn;
   const int tiles_m = (p.m + WBM - 1) / WBM;
   const int64_t blocks = (int64_t)tiles_n * tiles_m * batch;
-  // measured on MI355X (profiles/r01_gemm_tile_sweep_v2.txt): the 256-row tile wins only when there is
-  // enough K to amortise its single-block-per-CU prologue/epilogue and enough N to matter (in this
-  // model: the decoder's 512-channel 3x3 convolutions)
-  if (!force && (blocks < 192 || p.n < 512 || p.k < 2048)) return 0;
+  // measured on MI355X (profiles/r01_v6_gemm_tile_sweep.txt): one 8-wave block per CU has no second block
+  // to hide its prologue/epilogue behind, so the 256-row tile only wins with long K and either many
+  // rounds of blocks (the decoder's 256/512-channel 3x3 convolutions) or a grid that fits the 256 CUs
+  // once; wide GEGLU layers (N = 10240) win from K = 1280 because the 256x320 tile halves their
+  // L2->LDS traffic
+  if (!force) {
+    const bool fits = blocks >= 192 && blocks <= 256;
+    const bool conv_like = p.n >= 256 && p.k >= 2048 && (blocks >= 1024 || fits);
+    const bool wide_geglu = geglu && p.n >= 5120 && p.k >= 1280;
+    if (!conv_like && !wide_geglu) return 0;
+  }
   const int64_t nblk = (int64_t)tiles_n * 8 * ((tiles_m + 7) / 8);
   if (nblk > 0x7fffffffLL) return 0;
   dim3 grid((unsigned)nblk, 1, (unsigned)batch);

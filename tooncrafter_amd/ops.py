@@ -126,6 +126,10 @@ class HipOps:
         p.act, p.out_f32 = act, 1 if out_f32 else 0
         p.batch = batch
         p.stride_a, p.stride_w, p.stride_c = stride_a, stride_w, stride_c
+        nbytes = self.lib.tc_gemm_workspace(C.byref(p))          # > 0 only for split-K candidates (low-res layers)
+        if nbytes > 0:
+            ws = self._workspace(nbytes, a.device)
+            p.workspace, p.workspace_bytes = ws.data_ptr(), nbytes
         _lib.check(self.lib.tc_gemm_bf16(C.byref(p), _stream()), "tc_gemm_bf16")
         return out
 
