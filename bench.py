@@ -167,9 +167,19 @@ def measure_roofline(model, inp):
             un(None, ts, context=ctx2, fs=fs2, x_parts=[x2, cc2])
         n, ms, fl = probe.summary()
     achieved = fl / (ms * 1e-3) / 1e12
+    # HBM-side bytes per launch come from a separate rocprofv3 --pmc run of the same forward (counters cannot
+    # be read from inside this process); the committed summary of that run is quoted with its provenance
+    traffic, traffic_src = None, None
+    tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v6_pmc_unet_traffic.json")
+    if os.path.exists(tp):
+        with open(tp) as f:
+            tj = json.load(f)
+        traffic = round(tj["traffic_bytes_per_launch"])
+        traffic_src = ("profiles/r01_v6_pmc_unet_traffic.json: (2*FETCH_SIZE + WRITE_SIZE) per tc_gemm_bf16 launch, "
+                       "bytes; L2-miss traffic incl. Infinity-Cache hits")
     return {"bound": "mfma", "kernel": "gemm_kernel (tc_gemm_bf16: Linear / implicit-GEMM conv, all gather modes)",
             "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "launches": n, "avg_launch_us": round(ms * 1e3 / max(n, 1), 2),
             "algorithmic_tflop_per_unet_fwd_b2": round(fl / 1e12, 3), "gemm_ms_per_unet_fwd_b2": round(ms, 3)}
 
