@@ -15,6 +15,7 @@ script only calls its public classes and saves input/output tensors:
   unet_tiny.npz      UNetModel forward, 64-channel config, T=4, 8x8 latent
   decoder_tiny.npz   VideoDecoder forward via AutoencoderKL_Dualref.decode, ch=64, T=3
   ddim_tiny.npz      5-step DDIM trajectory (CFG 7.5, rescale 0.7, eta=1, injected noise)
+  resampler_tiny.npz image-token Resampler forward (2 layers, dim 128, 2 heads of 64, 4 queries x 3 frames) -- row f2
   ddim_mc_tiny.npz   4-step trajectory of samplers/ddim_multiplecond.py (three-way guidance: text 7.5,
                      image 3.0, rescale 0.7, eta=1, injected noise) -- SURVEY.md row f3
                      through LatentVisualDiffusion.apply_model, then decode_first_stage
@@ -289,5 +290,44 @@ def main():
     print("ddim_mc_tiny.npz written; final std", float(samples.std()), "finite", bool(torch.isfinite(samples).all()))
 
 
+def resampler_golden():
+    """Row f2: the reference Resampler (lvdm/modules/encoders/resampler.py) at a tiny width, plus the parameter
+    manifest of the full inference_512_v1.0.yaml configuration."""
+    import importlib.util
+    if REPO not in sys.path:
+        sys.path.insert(0, REPO)
+    from tooncrafter_amd import synth                        # noqa: E402  (ours: weight recipe only)
+    # the file imports nothing but torch/math: load it by path (the package __init__ chain is not needed)
+    spec = importlib.util.spec_from_file_location("ref_resampler", os.path.join(REF, "lvdm/modules/encoders/resampler.py"))
+    ref_rs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_rs)
+    assert ref_rs.__file__.startswith(REF), ref_rs.__file__
+    tiny = dict(dim=128, depth=2, dim_head=64, heads=2, num_queries=4, embedding_dim=96, output_dim=64, ff_mult=4,
+                video_length=3)
+    torch.manual_seed(0)
+    m = ref_rs.Resampler(**tiny).eval()
+    synth.fill_module_(m, prefix="image_proj_model.", seed=1234)
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(2, 9, 96, generator=g)
+    with torch.no_grad():
+        y = m(x)
+    np.savez_compressed(os.path.join(HERE, "resampler_tiny.npz"), x=x.numpy(), y=y.numpy(),
+                        n_params=np.int64(sum(p.numel() for p in m.parameters())))
+    full = dict(dim=1024, depth=4, dim_head=64, heads=12, num_queries=16, embedding_dim=1280, output_dim=1024,
+                ff_mult=4, video_length=16)
+    with torch.device("meta"):
+        mf = ref_rs.Resampler(**full)
+    man = {"tiny_cfg": tiny, "full_cfg": full,
+           "tiny": {k: list(v.shape) for k, v in m.state_dict().items()},
+           "full": {k: list(v.shape) for k, v in mf.state_dict().items()}}
+    with open(os.path.join(HERE, "resampler_manifest.json"), "w") as f:
+        json.dump(man, f, indent=0, sort_keys=True)
+    print("resampler_tiny.npz written; out std", float(y.std()), "params", sum(p.numel() for p in m.parameters()))
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["resampler"]:          # regenerate only the row-f2 fixtures
+        resampler_golden()
+    else:
+        main()
+        resampler_golden()

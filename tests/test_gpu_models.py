@@ -278,3 +278,36 @@ def test_encoder_tiny_vs_reference_golden(hip, tiny_sd):
     ez = rel_l2(z.cpu(), torch.from_numpy(g["z"]))
     print(f"tiny encoder: z rel-L2 {ez:.3e}; hidden states", [f"{e:.3e}" for e in errs])
     assert ez < 3e-2 and max(errs) < 3e-2
+
+
+def test_resampler_vs_reference_golden_and_full_size_oracle(hip):
+    """Row f2: image-token Resampler on the HIP kernels -- the reference's tiny forward, and the full
+    inference_512_v1.0.yaml configuration (4 layers, 12 heads, 256 queries over 257 CLIP tokens) against the
+    fp32 CPU oracle on identical synthetic weights."""
+    import json, os
+    from conftest import GOLDEN as GOLDEN_DIR
+    from oracle import resampler as ors
+    from tooncrafter_amd import synth
+    from tooncrafter_amd.lvdm.resampler import Resampler
+    man = json.load(open(os.path.join(GOLDEN_DIR, "resampler_manifest.json")))
+    g = load_golden("resampler_tiny.npz")
+
+    def run(cfg, x):
+        m = Resampler(**cfg).eval()
+        synth.fill_module_(m, prefix="image_proj_model.", seed=1234)
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        m = m.to(DEV)
+        with torch.no_grad():
+            y = _with_backend(hip, lambda: m(x.to(DEV)))
+        return y.cpu(), sd
+
+    y, _ = run(man["tiny_cfg"], torch.from_numpy(g["x"]))
+    e_tiny = rel_l2(y, torch.from_numpy(g["y"]))
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 257, 1280, generator=gen)
+    y, sd = run(man["full_cfg"], x)
+    ref = ors.resampler_forward(sd, x, heads=man["full_cfg"]["heads"])
+    e_full = rel_l2(y, ref)
+    print(f"resampler: tiny vs reference rel-L2 {e_tiny:.3e}; full config vs CPU oracle rel-L2 {e_full:.3e}")
+    assert tuple(y.shape) == (2, 256, 1024) and torch.isfinite(y).all()
+    assert e_tiny < 2e-2 and e_full < 2e-2

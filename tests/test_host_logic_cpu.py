@@ -182,6 +182,28 @@ def test_output_path_host_logic(emu_fp32, tmp_path):
     assert output.save_results_seperate("p", None, "x.mp4", fakedir) == []
 
 
+def test_resampler_host_logic(emu_fp32):
+    """Row f2: the Resampler mirror resolves under the reference's dotted path, carries the reference's
+    parameter names and shapes (full inference_512_v1.0.yaml configuration) and reproduces the reference's
+    tiny forward through the operator contract."""
+    from conftest import GOLDEN as GOLDEN_DIR
+    from tooncrafter_amd import synth
+    from tooncrafter_amd.utils import instantiate_from_config
+    man = json.load(open(os.path.join(GOLDEN_DIR, "resampler_manifest.json")))
+    with torch.device("meta"):
+        full = instantiate_from_config(dict(target="lvdm.modules.encoders.resampler.Resampler", params=man["full_cfg"]))
+    assert type(full).__module__ == "tooncrafter_amd.lvdm.resampler"
+    assert {k: list(v.shape) for k, v in full.state_dict().items()} == man["full"]
+    tiny = instantiate_from_config(dict(target="lvdm.modules.encoders.resampler.Resampler", params=man["tiny_cfg"])).eval()
+    assert {k: list(v.shape) for k, v in tiny.state_dict().items()} == man["tiny"]
+    synth.fill_module_(tiny, prefix="image_proj_model.", seed=1234)
+    g = load_golden("resampler_tiny.npz")
+    with torch.no_grad():
+        y = tiny(torch.from_numpy(g["x"]))
+    assert y.shape == g["y"].shape and y.dtype == torch.float32
+    assert rel_l2(y, torch.from_numpy(g["y"])) < 2e-2, rel_l2(y, torch.from_numpy(g["y"]))
+
+
 def test_step_scalars_first_step_is_finite():
     """Zero-terminal-SNR: at index S-1 the radicand 1 - a_prev - sigma^2 must be the tiny positive
     fp32 value the reference gets (+5.96e-8), not a negative one (NaN)."""

@@ -129,3 +129,17 @@ def test_encoder_tiny_matches_reference(tiny_sd):
         assert rel_l2(h, torch.from_numpy(g[f"hid{i}"])) < 2e-5, i
     fl = oenc.first_last_hidden(hidden, t=3)
     assert [tuple(x.shape[:3]) for x in fl] == [(1, 64, 2), (1, 128, 2), (1, 256, 2), (1, 256, 2), (1, 64, 2)]
+
+
+def test_resampler_tiny_matches_reference():
+    """Row f2: oracle/resampler.py against the real lvdm/modules/encoders/resampler.py."""
+    import json, os
+    from conftest import GOLDEN as GOLDEN_DIR
+    from oracle import resampler as ors
+    from tooncrafter_amd import synth
+    g = load_golden("resampler_tiny.npz")
+    man = json.load(open(os.path.join(GOLDEN_DIR, "resampler_manifest.json")))
+    sd = {k: synth.synth_tensor("image_proj_model." + k, tuple(shape), 1234, "cpu") for k, shape in man["tiny"].items()}
+    assert sum(v.numel() for v in sd.values()) == int(g["n_params"])
+    y = ors.resampler_forward(sd, torch.from_numpy(g["x"]), heads=man["tiny_cfg"]["heads"])
+    assert rel_l2(y, torch.from_numpy(g["y"])) < 2e-5

@@ -1,9 +1,9 @@
 """Synthetic stand-ins for the conditioning stack (NOT on the hot path).
 
-The reference's `FrozenOpenCLIPEmbedder`, `FrozenOpenCLIPImageEmbedderV2`
-(lvdm/modules/encoders/condition.py:174-234, 295-372) and `Resampler`
-(lvdm/modules/encoders/resampler.py:96-145) need open_clip + downloaded ViT-H/14
-weights, neither of which exists on the build or GPU boxes.  So that
+The reference's `FrozenOpenCLIPEmbedder` and `FrozenOpenCLIPImageEmbedderV2`
+(lvdm/modules/encoders/condition.py:174-234, 295-372) need the third-party open_clip
+package + downloaded ViT-H/14 weights, neither of which exists on the build or GPU
+boxes.  (The `Resampler` that follows them is real: lvdm/resampler.py.)  So that
 `configs/inference_512_v1.0.yaml` instantiates unmodified, these classes accept the
 same constructor kwargs and produce tensors of the right shape from a seeded
 generator.  They carry no parameters and do no real conditioning; a deployment
@@ -43,12 +43,3 @@ class FrozenOpenCLIPImageEmbedderV2(_Stub):
 
     def forward(self, image):
         return torch.cat([_seeded((1, 257, 1280), f"{float(im.float().mean()):.6f}", image.device) for im in image], 0)
-
-
-class Resampler(_Stub):
-    """(B, 257, 1280) -> (B, num_queries * video_length, output_dim)"""
-
-    def forward(self, x):
-        nq = self.kwargs.get("num_queries", 16) * self.kwargs.get("video_length", 16)
-        out_dim = self.kwargs.get("output_dim", 1024)
-        return torch.cat([_seeded((1, nq, out_dim), f"{float(xi.float().sum()):.4f}", x.device) for xi in x], 0)

@@ -17,7 +17,7 @@ MODULE_ALIASES = {
     "lvdm.modules.attention": "tooncrafter_amd.lvdm.attention",
     "lvdm.modules.networks.openaimodel3d": "tooncrafter_amd.lvdm.openaimodel3d",
     "lvdm.modules.encoders.condition": "tooncrafter_amd.lvdm.condition",
-    "lvdm.modules.encoders.resampler": "tooncrafter_amd.lvdm.condition",
+    "lvdm.modules.encoders.resampler": "tooncrafter_amd.lvdm.resampler",
     "utils.utils": "tooncrafter_amd.utils",
 }
 
