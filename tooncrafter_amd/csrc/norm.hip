@@ -14,17 +14,19 @@
 // (Folding gn_finalize into gn_stats -- last block of a sample reduces, arrival counter + agent-scope
 // __threadfence() in every block -- was built and measured: the 2048 L2 write-back/invalidate fences
 // per launch cost far more than the 5 us launch they save, +27 % on the whole clip.  Three launches stay.)
-// The chunk height is chosen on the host so that ~2048 blocks are in flight whatever the
+// The chunk height is chosen on the host so that ~512 blocks are in flight whatever the
 // tensor shape (clip-wide statistics have only B samples, per-frame ones B*T).
 // Algorithmic traffic: read x twice, write y once (the second read mostly hits the 256 MiB
 // Infinity Cache for UNet-sized tensors).
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int GN_THREADS = 256;
 constexpr int GN_MAX_SLOTS = 2;       // 8-channel vectors per thread per row pass -> C <= 4096
-constexpr int GN_TARGET_BLOCKS = 2048;
+constexpr int GN_TARGET_BLOCKS = 512;     // 2 per CU: measured best of 128..8192 (profiles/r01_v6_norm_bench.txt)
 constexpr int GN_MIN_ROWS = 8;
 
 struct GnGeo {
@@ -293,7 +295,9 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 
 // chunk height: ~GN_TARGET_BLOCKS blocks in flight, at least GN_MIN_ROWS rows each
 static inline void gn_chunking(int samples, int rows, int* nchunks, int* chunk_rows) {
-  int per_sample = GN_TARGET_BLOCKS / (samples > 0 ? samples : 1);
+  static const int target = [] { const char* e = getenv("TC_GN_BLOCKS"); const int v = e ? atoi(e) : 0;
+                                 return v > 0 ? v : GN_TARGET_BLOCKS; }();       // tuning override
+  int per_sample = target / (samples > 0 ? samples : 1);
   if (per_sample < 1) per_sample = 1;
   int max_chunks = (rows + GN_MIN_ROWS - 1) / GN_MIN_ROWS;
   int n = per_sample < max_chunks ? per_sample : max_chunks;
