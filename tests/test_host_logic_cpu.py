@@ -69,6 +69,36 @@ def test_decoder_tiny_host_logic(tiny_sd, emu_fp32):
     assert err < 2e-2, err
 
 
+def test_decoder_batch_of_clips_matches_single_clips(tiny_sd):
+    """SURVEY.md 8d config 4 (`perframe_ae=False` geometry): a batch of B clips goes through ONE decoder call
+    with timesteps=T -- the only geometry in which the dual-reference fusion (`k[:, [0]*(bt//b)]`,
+    autoencoder_dualref.py:282-292) sees each clip's own reference frames.  The result must equal decoding
+    every clip on its own (all normalisations and attentions are per clip)."""
+    from tooncrafter_amd.lvdm.autoencoder_dualref import VideoDecoder
+    prev = ops.set_backend(EmuOps(round_bf16=False))       # exact-arithmetic contract: isolates the host logic
+    try:
+        _check_decoder_batch(tiny_sd, VideoDecoder)
+    finally:
+        ops.set_backend(prev)
+
+
+def _check_decoder_batch(tiny_sd, VideoDecoder):
+    vd = VideoDecoder(**TINY_DD_CFG).eval()
+    vd.load_state_dict(sub_state_dict(tiny_sd, "first_stage_model.decoder."), strict=True)
+    g = torch.Generator().manual_seed(77)
+    z = torch.randn(2, 4, 3, 4, 6, generator=g)
+    from tooncrafter_amd import synth
+    refs = [torch.cat([a, b]) for a, b in zip(synth.synth_ref_context(1, 4, 6, ch=64, seed=11),
+                                              synth.synth_ref_context(1, 4, 6, ch=64, seed=12))]
+    with torch.no_grad():
+        both = vd.decode_clip(z, refs, scale=1.0 / 0.18215)
+        singles = [vd.decode_clip(z[i:i + 1], [r[i:i + 1] for r in refs], scale=1.0 / 0.18215) for i in range(2)]
+    assert both.shape == (2, 3, 3, 32, 48)
+    for i in range(2):
+        assert rel_l2(both[i:i + 1], singles[i]) < 1e-4, (i, rel_l2(both[i:i + 1], singles[i]))
+    assert rel_l2(both[0:1], singles[1]) > 0.1          # and the clips really differ
+
+
 def _tiny_model_cfg():
     return dict(
         rescale_betas_zero_snr=True, parameterization="v", linear_start=0.00085, linear_end=0.012,
