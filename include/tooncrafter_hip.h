@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TC_ABI_VERSION 4
+#define TC_ABI_VERSION 5
 
 enum {
   TC_OK = 0,
@@ -135,10 +135,13 @@ int tc_groupnorm(const tc_bf16* x, tc_bf16* y, const float* gamma, const float* 
 int tc_layernorm(const tc_bf16* x, tc_bf16* y, const float* gamma, const float* beta,
                  int32_t rows, int32_t c, float eps, void* stream);
 
-/* Row softmax fp32 [rows, n] -> bf16 [rows, ldo] (single-head d=512 mid attention of the
- * decoder, autoencoder_dualref.py:172-200, computed as GEMM + softmax + GEMM). */
-int tc_softmax_rows(const float* s, tc_bf16* p, int32_t rows, int32_t n, int32_t lds, int32_t ldo,
-                    void* stream);
+/* Row softmax fp32 [rows, n] -> bf16 [rows, ldo] for attention computed as GEMM + softmax + GEMM: the
+ * single-head d=512 mid attention of the decoder (autoencoder_dualref.py:172-200) and the OpenCLIP towers
+ * (head dim 80 / causal text attention, condition.py:215-231,340-372).  Columns [n, n_out) of p are written
+ * as zeros (K padding of the following P.V GEMM).  causal_period > 0: row r attends columns
+ * 0 .. (r mod causal_period) only -- the text tower's attn_mask -- masked columns get probability 0.  (ABI 5) */
+int tc_softmax_rows(const float* s, tc_bf16* p, int32_t rows, int32_t n, int32_t n_out, int32_t lds, int32_t ldo,
+                    int32_t causal_period, void* stream);
 
 /* (B, C, T, H, W) fp32, optionally two tensors concatenated on C, -> channels-last bf16
  * [B*T*H*W, c_pad] zero padded, times `scale`.  The hybrid-conditioning concat of

@@ -141,8 +141,16 @@ class EmuOps:
     def layernorm(self, x, gamma, beta, eps=1e-5):
         return self._out(F.layer_norm(_f(x), (x.shape[1],), gamma, beta, eps))
 
-    def softmax_rows(self, s):
-        return self._out(s.softmax(-1))
+    def softmax_rows(self, s, n=None, causal_period=0):
+        ld = s.shape[1]
+        n = ld if n is None else n
+        sc = s[:, :n].clone()
+        if causal_period > 0:
+            r = torch.arange(s.shape[0], device=s.device) % causal_period
+            sc = sc.masked_fill(torch.arange(n, device=s.device)[None, :] > r[:, None], float("-inf"))
+        out = torch.zeros_like(s)
+        out[:, :n] = sc.softmax(-1)
+        return self._out(out)
 
     # ------------------------------------------------------------------ layout / elementwise
     def nchw_to_rows(self, x0, x1=None, *, c_pad, scale=1.0):

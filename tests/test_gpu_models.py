@@ -311,3 +311,46 @@ def test_resampler_vs_reference_golden_and_full_size_oracle(hip):
     print(f"resampler: tiny vs reference rel-L2 {e_tiny:.3e}; full config vs CPU oracle rel-L2 {e_full:.3e}")
     assert tuple(y.shape) == (2, 256, 1024) and torch.isfinite(y).all()
     assert e_tiny < 2e-2 and e_full < 2e-2
+
+
+def test_openclip_towers_vs_oracle(hip):
+    """Row f2 (parity unpinned, see oracle/openclip.py): tiny towers and the full ViT-H/14 geometry -- vision
+    32 layers x 16 heads of 80 over 257 tokens, text 23 of 24 layers x 16 heads of 64 over 77 causal tokens --
+    against the fp32 CPU restatement on identical synthetic weights."""
+    from oracle import openclip as oclip
+    from test_host_logic_cpu import _tiny_towers
+    from tooncrafter_amd import synth
+    from tooncrafter_amd.lvdm.condition import FrozenOpenCLIPEmbedder, FrozenOpenCLIPImageEmbedderV2
+    g = torch.Generator().manual_seed(9)
+
+    def on_gpu(mod, fn):
+        sd = {k: v.detach().clone() for k, v in mod.state_dict().items()}
+        mod = mod.to(DEV)
+        with torch.no_grad():
+            y = _with_backend(hip, lambda: fn(mod))
+        return y.cpu(), sd
+
+    vis, txt = _tiny_towers()
+    img, tok = torch.randn(2, 3, 42, 42, generator=g), torch.randint(0, 50, (2, 7), generator=g)
+    yv, sdv = on_gpu(vis, lambda m: m.tokens(img.to(DEV)))
+    yt, sdt = on_gpu(txt, lambda m: m.tokens(tok.to(DEV), skip_last=1))
+    e_tv = rel_l2(yv, oclip.vision_tokens(sdv, img, heads=2))
+    e_tt = rel_l2(yt, oclip.text_tokens(sdt, tok, heads=2, skip_last=1))
+
+    emb_v = FrozenOpenCLIPImageEmbedderV2().eval()
+    synth.fill_module_(emb_v, prefix="embedder.", seed=1234)
+    img = torch.randn(1, 3, 224, 224, generator=g)
+    yv, sd = on_gpu(emb_v, lambda m: m.model.visual.tokens(img.to(DEV)))
+    sdv = {k[len("model.visual."):]: v for k, v in sd.items() if k.startswith("model.visual.")}
+    e_fv = rel_l2(yv, oclip.vision_tokens(sdv, img, heads=16))
+    del emb_v
+    emb_t = FrozenOpenCLIPEmbedder(layer="penultimate").eval()
+    synth.fill_module_(emb_t, prefix="cond_stage_model.", seed=1234)
+    tok = torch.randint(0, 49408, (2, 77), generator=g)
+    yt, sd = on_gpu(emb_t, lambda m: m(tok))
+    sdt = {k[len("model."):]: v for k, v in sd.items() if k.startswith("model.")}
+    e_ft = rel_l2(yt, oclip.text_tokens(sdt, tok, heads=16, skip_last=1))
+    print(f"openclip towers vs CPU restatement: tiny vision {e_tv:.3e} text {e_tt:.3e}; ViT-H/14 vision {e_fv:.3e} "
+          f"text {e_ft:.3e}")
+    assert tuple(yv.shape) == (1, 257, 1280) and tuple(yt.shape) == (2, 77, 1024)
+    assert max(e_tv, e_tt) < 2e-2 and max(e_fv, e_ft) < 3e-2

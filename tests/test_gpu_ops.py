@@ -222,6 +222,15 @@ def test_layernorm(hip, emu, rows, c):
 def test_softmax_rows(hip, emu):
     s = rnd(300, 2560, seed=46, dtype=torch.float32) * 3.0
     check(hip.softmax_rows(s), emu.softmax_rows(s), "softmax_rows")
+    # padded width (K padding of the following GEMM must come out as exact zeros) and the causal text mask
+    s2 = rnd(3 * 77, 80, seed=47, dtype=torch.float32) * 2.0
+    got = hip.softmax_rows(s2, n=77, causal_period=77)
+    check(got, emu.softmax_rows(s2, n=77, causal_period=77), "softmax_rows causal padded")
+    assert float(got[:, 77:].abs().max()) == 0.0 and float(got[0, 1:].abs().max()) == 0.0 and float(got[0, 0]) == 1.0
+    s3 = rnd(514, 264, seed=48, dtype=torch.float32)
+    got = hip.softmax_rows(s3, n=257)
+    check(got, emu.softmax_rows(s3, n=257), "softmax_rows padded")
+    assert float(got[:, 257:].abs().max()) == 0.0
 
 
 # --------------------------------------------------------------------------- layout / elementwise

@@ -271,11 +271,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
 // ---------------------------------------------------------------------------------------
 // Row softmax fp32 -> bf16, one block per row (rows are L = 2560 wide in the decoder).
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, bf16_t* __restrict__ p,
-                                                          int n, int lds, int ldo) {
+                                                          int n_all, int n_out, int lds, int ldo, int causal_period) {
   __shared__ float redm[4], reds[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* sr = s + (int64_t)blockIdx.x * lds;
   bf16_t* pr = p + (int64_t)blockIdx.x * ldo;
+  int n = n_all;
+  if (causal_period > 0) n = min(n_all, (int)(blockIdx.x % causal_period) + 1);
   float mx = -1e30f;
   for (int i = tid; i < n; i += 256) mx = fmaxf(mx, sr[i]);
   mx = wave_max(mx);
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   if (lane == 0) reds[wave] = sum;
   __syncthreads();
   const float inv = 1.0f / (reds[0] + reds[1] + reds[2] + reds[3]);
-  for (int i = tid; i < n; i += 256) pr[i] = (bf16_t)(__expf(sr[i] - mx) * inv);
+  for (int i = tid; i < n_out; i += 256) pr[i] = i < n ? (bf16_t)(__expf(sr[i] - mx) * inv) : (bf16_t)0.f;
 }
 
 }  // namespace
@@ -352,11 +354,11 @@ extern "C" int tc_layernorm(const tc_bf16* x, tc_bf16* y, const float* gamma, co
   return TC_OK;
 }
 
-extern "C" int tc_softmax_rows(const float* s, tc_bf16* p, int32_t rows, int32_t n, int32_t lds, int32_t ldo,
-                               void* stream) {
-  if (!s || !p || rows <= 0 || n <= 0 || lds < n || ldo < n) return TC_EINVAL;
+extern "C" int tc_softmax_rows(const float* s, tc_bf16* p, int32_t rows, int32_t n, int32_t n_out, int32_t lds,
+                               int32_t ldo, int32_t causal_period, void* stream) {
+  if (!s || !p || rows <= 0 || n <= 0 || n_out < n || lds < n || ldo < n_out || causal_period < 0) return TC_EINVAL;
   hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), s,
-                     reinterpret_cast<bf16_t*>(p), n, lds, ldo);
+                     reinterpret_cast<bf16_t*>(p), n, n_out, lds, ldo, causal_period);
   TC_LAUNCH_CHECK();
   return TC_OK;
 }

@@ -197,13 +197,17 @@ class HipOps:
                                          x.shape[0], x.shape[1], float(eps), _stream()), "tc_layernorm")
         return y
 
-    def softmax_rows(self, s):
-        """fp32 [rows, n] -> bf16 probabilities [rows, n]."""
+    def softmax_rows(self, s, n=None, causal_period=0):
+        """fp32 scores [rows, ld] -> bf16 probabilities [rows, ld]: softmax over the first `n` columns
+        (default: all), the padding columns [n, ld) written as zeros; `causal_period` > 0: row r attends
+        columns 0..(r mod period) only."""
         if s.dtype != torch.float32 or s.dim() != 2 or not s.is_contiguous() or not s.is_cuda:
             raise ValueError("softmax_rows: contiguous fp32 CUDA [rows, n]")
+        ld = s.shape[1]
+        n = ld if n is None else int(n)
         p = torch.empty(s.shape, dtype=BF16, device=s.device)
-        _lib.check(self.lib.tc_softmax_rows(s.data_ptr(), p.data_ptr(), s.shape[0], s.shape[1], s.shape[1],
-                                            s.shape[1], _stream()), "tc_softmax_rows")
+        _lib.check(self.lib.tc_softmax_rows(s.data_ptr(), p.data_ptr(), s.shape[0], n, ld, ld, ld,
+                                            int(causal_period), _stream()), "tc_softmax_rows")
         return p
 
     # ------------------------------------------------------------------ layout / elementwise
