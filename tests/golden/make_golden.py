@@ -15,6 +15,8 @@ script only calls its public classes and saves input/output tensors:
   unet_tiny.npz      UNetModel forward, 64-channel config, T=4, 8x8 latent
   decoder_tiny.npz   VideoDecoder forward via AutoencoderKL_Dualref.decode, ch=64, T=3
   ddim_tiny.npz      5-step DDIM trajectory (CFG 7.5, rescale 0.7, eta=1, injected noise)
+  pipeline_tiny.npz  scripts/evaluation/inference.py::image_guided_synthesis on the tiny model with the deterministic
+                     conditioner stand-ins of pipeline_stubs.py (interp mode, 3 DDIM steps, CFG 7.5) -- the caller row
   resampler_tiny.npz image-token Resampler forward (2 layers, dim 128, 2 heads of 64, 4 queries x 3 frames) -- row f2
   ddim_mc_tiny.npz   4-step trajectory of samplers/ddim_multiplecond.py (three-way guidance: text 7.5,
                      image 3.0, rescale 0.7, eta=1, injected noise) -- SURVEY.md row f3
@@ -290,6 +292,56 @@ def main():
     print("ddim_mc_tiny.npz written; final std", float(samples.std()), "finite", bool(torch.isfinite(samples).all()))
 
 
+def pipeline_golden():
+    """The caller of the hot path: the reference's own image_guided_synthesis (inference.py:180-277) end to end."""
+    import importlib.util
+    install_stubs()
+    _mod("omegaconf", OmegaConf=type("OmegaConf", (), {}))
+    for pth in (REF, REPO, HERE):
+        if pth not in sys.path:
+            sys.path.insert(0, pth)
+    sys.path.insert(0, REF)
+    from tooncrafter_amd import synth                        # noqa: E402  (ours: weight recipe only)
+    from utils.utils import instantiate_from_config          # noqa: E402  (reference)
+    from lvdm.models.samplers import ddim as ref_ddim        # noqa: E402
+    from lvdm import distributions as ref_dist               # noqa: E402
+    import pipeline_stubs as stubs                           # noqa: E402
+    assert ref_ddim.__file__.startswith(REF)
+    spec = importlib.util.spec_from_file_location("ref_inference", os.path.join(REF, "scripts/evaluation/inference.py"))
+    ref_inf = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_inf)
+    torch.manual_seed(0)
+    torch.set_grad_enabled(False)
+    cfg = tiny_config()
+    model = instantiate_from_config(cfg.model).eval()
+    model.perframe_ae = True
+    synth.fill_module_(model, seed=1234)
+    T = cfg.model.params.unet_config.params.temporal_length
+    model.embedder = stubs.StubEmbedder()
+    model.image_proj_model = stubs.StubImageProj(T)
+    model.get_learned_conditioning = lambda prompts: stubs.stub_text(prompts)
+    ref_dist.DiagonalGaussianDistribution.sample = lambda self, noise=None: self.mean       # deterministic posterior
+    ref_ddim.DDIMSampler.register_buffer = lambda self, n, a: setattr(self, n, a)
+    g = torch.Generator().manual_seed(61)
+    fa, fb = (torch.randn(1, 3, 1, 64, 64, generator=g).clamp(-1, 1) for _ in range(2))
+    videos = torch.cat([fa.repeat(1, 1, T // 2, 1, 1), fb.repeat(1, 1, T // 2, 1, 1)], dim=2)   # load_data_prompts interp
+    S = 3
+    noises = [torch.randn(1, 4, T, 8, 8, generator=g) for _ in range(S)]
+    it = iter(noises)
+    ref_ddim.noise_like = lambda shape, device, repeat=False: next(it)
+    torch.manual_seed(2024)                                   # x_T = the first torch.randn of ddim_sampling
+    out = ref_inf.image_guided_synthesis(model, ["ignored"], videos, [1, 4, T, 8, 8], n_samples=1, ddim_steps=S,
+                                         ddim_eta=1.0, unconditional_guidance_scale=7.5, cfg_img=None, fs=10,
+                                         text_input=False, multiple_cond_cfg=False, loop=False, interp=True,
+                                         timestep_spacing="uniform_trailing", guidance_rescale=0.7)
+    z, hs = ref_inf.get_latent_z_with_hidden_states(model, videos)
+    np.savez_compressed(os.path.join(HERE, "pipeline_tiny.npz"), videos=videos.numpy(),
+                        noises=torch.stack(noises).numpy(), out=out.numpy(), z=z.numpy(),
+                        hs_shapes=np.asarray([list(h.shape) for h in hs]),
+                        **{f"hs{i}": h[:, ::4, :, ::4, ::4].numpy() for i, h in enumerate(hs)})      # subsampled: small fixture
+    print("pipeline_tiny.npz written; out", tuple(out.shape), "std", float(out.std()), "finite", bool(torch.isfinite(out).all()))
+
+
 def resampler_golden():
     """Row f2: the reference Resampler (lvdm/modules/encoders/resampler.py) at a tiny width, plus the parameter
     manifest of the full inference_512_v1.0.yaml configuration."""
@@ -328,6 +380,9 @@ def resampler_golden():
 if __name__ == "__main__":
     if sys.argv[1:] == ["resampler"]:          # regenerate only the row-f2 fixtures
         resampler_golden()
+    elif sys.argv[1:] == ["pipeline"]:         # regenerate only the caller-row fixture
+        pipeline_golden()
     else:
         main()
         resampler_golden()
+        print("run `python make_golden.py pipeline` separately (it patches the reference's posterior sampling)")

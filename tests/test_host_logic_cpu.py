@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import GOLDEN as GOLDEN_DIR
 from conftest import (FULL_DD_CFG, FULL_UNET_CFG, TINY_DD_CFG, TINY_UNET_CFG, load_golden, rel_l2,
                       sub_state_dict)
 from emu_ops import EmuOps
@@ -295,6 +296,54 @@ def test_openclip_conditioners_resolve_and_carry_open_clip_names():
     import pytest
     with pytest.raises(RuntimeError):
         t.tokenize(["a prompt"])                                          # no BPE vocabulary in this image
+    tok = t.tokenize(["", ""])                                            # the scripts' default prompt needs none
+    assert tok.shape == (2, 77) and tok[0, :3].tolist() == [49406, 49407, 0] and int(tok.sum()) == 2 * (49406 + 49407)
+
+
+def test_pipeline_matches_reference_image_guided_synthesis(tiny_sd, emu_fp32):
+    """The caller row: tooncrafter_amd.pipeline.image_guided_synthesis against the reference's own function
+    (scripts/evaluation/inference.py:180-277) run on the tiny model with the shared deterministic conditioner
+    stand-ins -- conditioning assembly, first/last-frame encode (2 frames instead of T), c_concat, uncond branch,
+    sampler call, both decodes and the centre-frame splice."""
+    import sys
+    sys.path.insert(0, GOLDEN_DIR)
+    import pipeline_stubs as stubs
+    from tooncrafter_amd import pipeline
+    from tooncrafter_amd.lvdm import autoencoder as my_ae, ddim as my_ddim
+    from tooncrafter_amd.utils import instantiate_from_config
+    g = load_golden("pipeline_tiny.npz")
+    model = instantiate_from_config(dict(target="lvdm.models.ddpm3d.LatentVisualDiffusion", params=_tiny_model_cfg())).eval()
+    model.load_state_dict(tiny_sd, strict=False)
+    model.embedder = stubs.StubEmbedder()
+    model.image_proj_model = stubs.StubImageProj(4)
+    model.get_learned_conditioning = lambda prompts: stubs.stub_text(prompts)
+    videos = torch.from_numpy(g["videos"])
+    it = iter(torch.from_numpy(g["noises"]))
+    old_noise, old_sample = my_ddim.noise_like, my_ae.DiagonalGaussianDistribution.sample
+    my_ddim.noise_like = lambda shape, device, repeat=False: next(it)
+    my_ae.DiagonalGaussianDistribution.sample = lambda self, noise=None: self.mean        # as patched in the golden run
+    try:
+        with torch.no_grad():
+            z, hs = pipeline.get_latent_z_with_hidden_states(model, videos)
+            torch.manual_seed(2024)                                                       # x_T, as in the golden run
+            out = pipeline.image_guided_synthesis(model, ["ignored"], videos, [1, 4, 4, 8, 8], n_samples=1,
+                                                  ddim_steps=3, ddim_eta=1.0, unconditional_guidance_scale=7.5,
+                                                  cfg_img=None, fs=10, text_input=False, multiple_cond_cfg=False,
+                                                  loop=False, interp=True, timestep_spacing="uniform_trailing",
+                                                  guidance_rescale=0.7)
+    finally:
+        my_ddim.noise_like, my_ae.DiagonalGaussianDistribution.sample = old_noise, old_sample
+    # latents of the two frames the reference keeps, and the first/last hidden states
+    zr = torch.from_numpy(g["z"])
+    assert z.shape == zr.shape
+    assert rel_l2(z[:, :, [0, -1]], zr[:, :, [0, -1]]) < 2e-2 and float(z[:, :, 1:-1].abs().max()) == 0.0
+    assert [list(h.shape) for h in hs] == g["hs_shapes"].tolist()
+    for i, h in enumerate(hs):
+        assert rel_l2(h[:, ::4, :, ::4, ::4], torch.from_numpy(g[f"hs{i}"])) < 2e-2, i
+    ref = torch.from_numpy(g["out"])
+    assert out.shape == ref.shape == (1, 1, 3, 4, 64, 64)
+    err = rel_l2(out, ref)
+    assert err < 0.15, err                     # CFG-7.5 trajectory bound (see the DDIM tests)
 
 
 def test_step_scalars_first_step_is_finite():

@@ -7,7 +7,7 @@ this image lacks, so they are rebuilt here from the published ViT-H/14 hyper-par
 parameter names; two host-side pieces of the reference cannot be reproduced exactly without their packages and
 say so loudly instead of guessing:
   * tokenisation (`open_clip.tokenize`, BPE vocabulary file): `forward(text)` accepts already-tokenised
-    int64 (B, 77) tensors; strings need `open_clip` importable;
+    int64 (B, 77) tensors and the empty prompt "" (the scripts' default); other strings need `open_clip`;
   * image resize (`kornia.geometry.resize(..., 'bicubic', align_corners=True, antialias=True)`): replaced by
     `torch.nn.functional.interpolate(bicubic, align_corners=True, antialias=True)` -- a different antialias
     filter, i.e. a documented deviation of the preprocessing, not of the towers.
@@ -46,6 +46,13 @@ class FrozenOpenCLIPEmbedder(AbstractEncoder):
             p.requires_grad = False
 
     def tokenize(self, text):
+        text = [text] if isinstance(text, str) else list(text)
+        if all(t == "" for t in text):
+            # the only prompts the interpolation scripts use by default (inference.py:186-187,209-210):
+            # "" tokenises to <start_of_text>=49406, <end_of_text>=49407, zero padding (open_clip/tokenizer.py)
+            tok = torch.zeros((len(text), self.max_length), dtype=torch.long)
+            tok[:, 0], tok[:, 1] = 49406, 49407
+            return tok
         try:
             import open_clip
         except Exception as e:
