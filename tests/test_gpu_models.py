@@ -354,3 +354,43 @@ def test_openclip_towers_vs_oracle(hip):
           f"text {e_ft:.3e}")
     assert tuple(yv.shape) == (1, 257, 1280) and tuple(yt.shape) == (2, 77, 1024)
     assert max(e_tv, e_tt) < 2e-2 and max(e_fv, e_ft) < 3e-2
+
+
+def test_pipeline_vs_reference_image_guided_synthesis(hip, tiny_sd):
+    """The caller row on the GPU: conditioning -> 2-frame encode -> DDIM (CFG 7.5) -> two decodes -> splice,
+    against the reference's own image_guided_synthesis (tests/golden/pipeline_tiny.npz)."""
+    import sys
+    from conftest import GOLDEN as GOLDEN_DIR
+    sys.path.insert(0, GOLDEN_DIR)
+    import pipeline_stubs as stubs
+    from tooncrafter_amd import pipeline
+    from tooncrafter_amd.lvdm import autoencoder as my_ae, ddim as my_ddim
+    g = load_golden("pipeline_tiny.npz")
+    model = _tiny_pipeline(tiny_sd)
+    model.embedder = stubs.StubEmbedder()
+    model.image_proj_model = stubs.StubImageProj(4)
+    model.get_learned_conditioning = lambda prompts: stubs.stub_text(prompts, DEV)
+    videos = torch.from_numpy(g["videos"]).to(DEV)
+    noises = torch.from_numpy(g["noises"]).to(DEV)
+    torch.manual_seed(2024)
+    x_T = torch.randn(1, 4, 4, 8, 8)                 # the CPU draw the golden run used (device generators differ)
+
+    def run():
+        it = iter(noises)
+        old_noise, old_sample = my_ddim.noise_like, my_ae.DiagonalGaussianDistribution.sample
+        my_ddim.noise_like = lambda shape, device, repeat=False: next(it)
+        my_ae.DiagonalGaussianDistribution.sample = lambda self, noise=None: self.mean
+        try:
+            return pipeline.image_guided_synthesis(model, ["ignored"], videos, [1, 4, 4, 8, 8], n_samples=1,
+                                                   ddim_steps=3, ddim_eta=1.0, unconditional_guidance_scale=7.5,
+                                                   cfg_img=None, fs=10, text_input=False, multiple_cond_cfg=False,
+                                                   loop=False, interp=True, timestep_spacing="uniform_trailing",
+                                                   guidance_rescale=0.7, x_T=x_T.to(DEV))
+        finally:
+            my_ddim.noise_like, my_ae.DiagonalGaussianDistribution.sample = old_noise, old_sample
+
+    with torch.no_grad():
+        out = _with_backend(hip, run)
+    err = rel_l2(out.cpu(), torch.from_numpy(g["out"]))
+    print(f"image_guided_synthesis (tiny, 3 steps, CFG 7.5) vs reference: rel-L2 {err:.3e}")
+    assert tuple(out.shape) == (1, 1, 3, 4, 64, 64) and torch.isfinite(out).all() and err < 0.15
