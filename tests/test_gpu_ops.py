@@ -302,6 +302,18 @@ def test_gemm_split_k_low_resolution_layers(hip, emu):
     assert hip.lib.tc_gemm_workspace(C.byref(p)) == 0                         # short K: 64x64 tiles instead
 
 
+def test_gemm_chunked_tile_order_for_wide_n(hip, emu):
+    """Layers whose weight matrix outgrows one XCD's L2 (N*K*2 > 4 MiB, >= 16 N-tiles) walk their tiles in
+    chunks of 8 N-tiles x all M-tiles of the XCD: a different, still bijective block -> tile map.  Ragged M,
+    an N-tile count that is not a multiple of 8, both tile families."""
+    a, w, b = rnd(1100, 1024, seed=80), rnd(2680, 1024, seed=81, scale=1024 ** -0.5), rnd(2680, seed=82, dtype=torch.float32)
+    check(hip.gemm(a, w, b, act=ACT_SILU), emu.gemm(a, w, b, act=ACT_SILU), "chunked order 128x128, 21 N-tiles")
+    a, w, b = rnd(700, 1280, seed=83), rnd(5120, 1280, seed=84, scale=1280 ** -0.5), rnd(5120, seed=85, dtype=torch.float32)
+    check(hip.gemm(a, w, b, act=ACT_GEGLU), emu.gemm(a, w, b, act=ACT_GEGLU), "chunked order 256x320 GEGLU, 16 N-tiles")
+    a, w = rnd(2100, 640, seed=86), rnd(5120, 640, seed=87, scale=640 ** -0.5)
+    check(hip.gemm(a, w, None, act=ACT_GEGLU), emu.gemm(a, w, None, act=ACT_GEGLU), "chunked order 128x128 GEGLU, 40 N-tiles")
+
+
 @pytest.mark.parametrize("resc,cfg_img", [(0.7, 3.0), (0.0, None)])
 def test_ddim_step_three_way_guidance(hip, emu, resc, cfg_img):
     """Row f3: e_uncond + cfg_img (e_uncond_img - e_uncond) + s (e_cond - e_uncond_img), then rescale."""

@@ -160,7 +160,7 @@ __device__ __forceinline__ void epilogue_tail(const TcGemmParams& p, const float
 }
 
 template <int GATHER, int TM, int TN>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams pin, const int splits) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams pin, const int splits, const int order) {
   // split-K (blockIdx.y = slice of the K loop): the block emits its raw fp32 partial tile into the
   // workspace -- the plain epilogue with every fused term switched off -- and splitk_reduce_kernel
   // finishes the job
@@ -187,10 +187,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams pin, co
 
   const int tiles_n = (p.n + BN - 1) / BN;
   const int tiles_m = (p.m + BM - 1) / BM;
-  const int xcd = blockIdx.x & 7;
-  const int slot = blockIdx.x >> 3;
-  const int tile_m = (slot / tiles_n) * 8 + xcd;
-  const int tile_n = slot % tiles_n;
+  int tile_m, tile_n;
+  tc_tile_of_block(blockIdx.x, tiles_m, tiles_n, order, tile_m, tile_n);
   if (tile_m >= tiles_m) return;
 
   const int64_t bz = blockIdx.z;
@@ -476,12 +474,13 @@ extern "C" int tc_gemm_bf16(const TcGemmParams* pp, void* stream) {
   const int64_t nblk = (int64_t)tiles_n * 8 * ((tiles_m + 7) / 8);
   if (nblk > 0x7fffffffLL || batch > 65535) return TC_ESHAPE;
   dim3 grid((unsigned)nblk, (unsigned)splits, (unsigned)batch), block(256);
+  const int order = tc_gemm_tile_order(p, tiles_n);
 #define TC_LAUNCH_GEMM(G)                                                                           \
   do {                                                                                              \
-    if (tm == 2 && tn == 2) hipLaunchKernelGGL((gemm_kernel<G, 2, 2>), grid, block, 0, s, p, splits);      \
-    else if (tm == 2) hipLaunchKernelGGL((gemm_kernel<G, 2, 1>), grid, block, 0, s, p, splits);            \
-    else if (tn == 2) hipLaunchKernelGGL((gemm_kernel<G, 1, 2>), grid, block, 0, s, p, splits);            \
-    else hipLaunchKernelGGL((gemm_kernel<G, 1, 1>), grid, block, 0, s, p, splits);                         \
+    if (tm == 2 && tn == 2) hipLaunchKernelGGL((gemm_kernel<G, 2, 2>), grid, block, 0, s, p, splits, order);      \
+    else if (tm == 2) hipLaunchKernelGGL((gemm_kernel<G, 2, 1>), grid, block, 0, s, p, splits, order);            \
+    else if (tn == 2) hipLaunchKernelGGL((gemm_kernel<G, 1, 2>), grid, block, 0, s, p, splits, order);            \
+    else hipLaunchKernelGGL((gemm_kernel<G, 1, 1>), grid, block, 0, s, p, splits, order);                         \
   } while (0)
   switch (p.gather) {
     case TC_GATHER_LINEAR: TC_LAUNCH_GEMM(TC_GATHER_LINEAR); break;

@@ -2,6 +2,8 @@
 #pragma once
 #include "common.h"
 
+#include <stdlib.h>
+
 constexpr int TC_BK = 64;   // K-step of every GEMM kernel: one 128-byte LDS row per tile row
 
 // Byte offset of 16-byte chunk `chunk` (0..7) of tile row `row` in the LDS image.  Rows are 128 B; the
@@ -47,6 +49,43 @@ __device__ __forceinline__ u32x4 buf_load16(tc_rsrc_t rsrc, uint32_t voff, uint3
 // silently drops a __global__ template that names this builtin directly.
 __device__ __forceinline__ void glds16(tc_rsrc_t rsrc, char* lds, uint32_t voff, uint32_t soff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+
+// Block -> output tile.  Blocks are dealt round-robin to the 8 XCDs (blockIdx & 7), each with its own L2, so
+// M-tile t always lives on XCD t & 7 and its A rows are fetched into one L2 only.  Within an XCD:
+//   order 0: all N-tiles of an M-tile back to back (A stays hot; W is re-streamed once per M-tile -- fine
+//            while the weight matrix fits the 4 MiB L2);
+//   order 1: N-tiles in chunks of 8: for each chunk, all M-tiles of the XCD, so ~64 co-resident blocks cover
+//            8 M-tiles x 8 N-tiles and both operands are re-read from L2, not from the fabric (for the wide-N
+//            layers whose W does not fit L2).
+__device__ __forceinline__ void tc_tile_of_block(int bid, int tiles_m, int tiles_n, int order, int& tile_m, int& tile_n) {
+  const int xcd = bid & 7;
+  const int slot = bid >> 3;
+  if (order == 0) {
+    tile_m = (slot / tiles_n) * 8 + xcd;
+    tile_n = slot % tiles_n;
+    return;
+  }
+  constexpr int GN = 8;
+  const int tm_x = (tiles_m + 7) >> 3;                 // M-tiles per XCD (upper bound; surplus blocks exit)
+  const int full = (tiles_n / GN) * GN;
+  int m_local;
+  if (slot < tm_x * full) {
+    const int c = slot / (tm_x * GN), r = slot - c * (tm_x * GN);
+    m_local = r / GN;
+    tile_n = c * GN + (r - m_local * GN);
+  } else {
+    const int rem = tiles_n - full, r = slot - tm_x * full;
+    m_local = r / rem;
+    tile_n = full + (r - m_local * rem);
+  }
+  tile_m = m_local * 8 + xcd;
+}
+
+// host side: order 1 when the weight matrix outgrows one XCD's L2 and there are enough N-tiles to chunk
+inline int tc_gemm_tile_order(const TcGemmParams& p, int tiles_n) {
+  static const bool enabled = [] { const char* e = getenv("TC_GEMM_ORDER"); return !(e && e[0] == '0'); }();
+  return (enabled && tiles_n >= 16 && (int64_t)p.n * p.ldw * 2 > (4 << 20)) ? 1 : 0;
 }
 
 // Per-thread gather state for `R` rows of the A tile.

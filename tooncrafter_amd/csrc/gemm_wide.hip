@@ -24,7 +24,7 @@ constexpr int WBM = 256;
 constexpr int WTHREADS = 512;
 
 template <int GATHER, int TNW>
-__global__ __launch_bounds__(WTHREADS, 2) void gemm_wide_kernel(const TcGemmParams p) {
+__global__ __launch_bounds__(WTHREADS, 2) void gemm_wide_kernel(const TcGemmParams p, const int order) {
   constexpr int BN = 64 * TNW;
   constexpr int WN = 32 * TNW;                         // columns per wave
   constexpr int STAGE_BYTES = (WBM + BN) * TC_BK * 2;  // 72 KiB at BN = 320
@@ -41,10 +41,8 @@ __global__ __launch_bounds__(WTHREADS, 2) void gemm_wide_kernel(const TcGemmPara
 
   const int tiles_n = (p.n + BN - 1) / BN;
   const int tiles_m = (p.m + WBM - 1) / WBM;
-  const int xcd = blockIdx.x & 7;
-  const int slot = blockIdx.x >> 3;
-  const int tile_m = (slot / tiles_n) * 8 + xcd;
-  const int tile_n = slot % tiles_n;
+  int tile_m, tile_n;
+  tc_tile_of_block(blockIdx.x, tiles_m, tiles_n, order, tile_m, tile_n);
   if (tile_m >= tiles_m) return;
 
   const int64_t bz = blockIdx.z;
@@ -269,10 +267,11 @@ __global__ __launch_bounds__(WTHREADS, 2) void gemm_wide_kernel(const TcGemmPara
 template <int TNW>
 void launch_wide(const TcGemmParams& p, dim3 grid, hipStream_t s) {
   dim3 block(WTHREADS);
+  const int order = tc_gemm_tile_order(p, (p.n + 64 * TNW - 1) / (64 * TNW));
   switch (p.gather) {
-    case TC_GATHER_LINEAR: hipLaunchKernelGGL((gemm_wide_kernel<TC_GATHER_LINEAR, TNW>), grid, block, 0, s, p); break;
-    case TC_GATHER_CONV3x3: hipLaunchKernelGGL((gemm_wide_kernel<TC_GATHER_CONV3x3, TNW>), grid, block, 0, s, p); break;
-    default: hipLaunchKernelGGL((gemm_wide_kernel<TC_GATHER_CONVT3, TNW>), grid, block, 0, s, p); break;
+    case TC_GATHER_LINEAR: hipLaunchKernelGGL((gemm_wide_kernel<TC_GATHER_LINEAR, TNW>), grid, block, 0, s, p, order); break;
+    case TC_GATHER_CONV3x3: hipLaunchKernelGGL((gemm_wide_kernel<TC_GATHER_CONV3x3, TNW>), grid, block, 0, s, p, order); break;
+    default: hipLaunchKernelGGL((gemm_wide_kernel<TC_GATHER_CONVT3, TNW>), grid, block, 0, s, p, order); break;
   }
 }
 
