@@ -300,7 +300,7 @@ def test_openclip_conditioners_resolve_and_carry_open_clip_names():
     assert tok.shape == (2, 77) and tok[0, :3].tolist() == [49406, 49407, 0] and int(tok.sum()) == 2 * (49406 + 49407)
 
 
-def test_pipeline_matches_reference_image_guided_synthesis(tiny_sd, emu_fp32):
+def test_pipeline_matches_reference_image_guided_synthesis(tiny_sd):
     """The caller row: tooncrafter_amd.pipeline.image_guided_synthesis against the reference's own function
     (scripts/evaluation/inference.py:180-277) run on the tiny model with the shared deterministic conditioner
     stand-ins -- conditioning assembly, first/last-frame encode (2 frames instead of T), c_concat, uncond branch,
@@ -312,6 +312,16 @@ def test_pipeline_matches_reference_image_guided_synthesis(tiny_sd, emu_fp32):
     from tooncrafter_amd.lvdm import autoencoder as my_ae, ddim as my_ddim
     from tooncrafter_amd.utils import instantiate_from_config
     g = load_golden("pipeline_tiny.npz")
+    # exact-arithmetic operator contract (bf16 weights only): a 3-step CFG-7.5 trajectory amplifies bf16
+    # activation noise to ~0.13 (measured), which would hide an orchestration error; this way the bound is tight
+    prev = ops.set_backend(EmuOps(round_bf16=False))
+    try:
+        _check_pipeline(tiny_sd, g, stubs, pipeline, my_ae, my_ddim, instantiate_from_config)
+    finally:
+        ops.set_backend(prev)
+
+
+def _check_pipeline(tiny_sd, g, stubs, pipeline, my_ae, my_ddim, instantiate_from_config):
     model = instantiate_from_config(dict(target="lvdm.models.ddpm3d.LatentVisualDiffusion", params=_tiny_model_cfg())).eval()
     model.load_state_dict(tiny_sd, strict=False)
     model.embedder = stubs.StubEmbedder()
@@ -343,7 +353,7 @@ def test_pipeline_matches_reference_image_guided_synthesis(tiny_sd, emu_fp32):
     ref = torch.from_numpy(g["out"])
     assert out.shape == ref.shape == (1, 1, 3, 4, 64, 64)
     err = rel_l2(out, ref)
-    assert err < 0.15, err                     # CFG-7.5 trajectory bound (see the DDIM tests)
+    assert err < 3e-2, err
 
 
 def test_step_scalars_first_step_is_finite():
