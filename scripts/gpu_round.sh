@@ -14,6 +14,7 @@ for s in $STAGES; do
   t0=$(date +%s)
   case $s in
     ops)    timeout 900 python -m pytest tests/test_gpu_ops.py -m gpu -q -s -p no:cacheprovider > $OUT/ops.log 2>&1 ;;
+    props)  timeout 600 python -m pytest tests/test_gpu_properties.py -m gpu -q -s -p no:cacheprovider > $OUT/props.log 2>&1 ;;
     models) timeout 1500 python -m pytest tests/test_gpu_models.py -m gpu -q -s -p no:cacheprovider > $OUT/models.log 2>&1 ;;
     smoke)  timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1 ;;
     bench)  timeout 900 python bench.py --steps 1 --warmup 1 --ddim-steps 4 --no-cpu-baseline > $OUT/bench_short.log 2>&1 ;;
