@@ -24,6 +24,7 @@ for s in $STAGES; do
     tilesweep) timeout 900 bash scripts/gemm_tile_sweep.sh > $OUT/tile_sweep.log 2>&1 ;;
     pmcunet) (cd /tmp && for ctr in FETCH_SIZE WRITE_SIZE; do timeout -k 5 150 rocprofv3 --kernel-trace --pmc $ctr -d $OLDPWD/$OUT/pmcunet_$ctr -o pmc -- python $OLDPWD/scripts/pmc_unet.py 2 > $OLDPWD/$OUT/pmcunet_$ctr.log 2>&1; python $OLDPWD/scripts/pmc_parse.py "$(find $OLDPWD/$OUT/pmcunet_$ctr -name '*.db' | head -1)" 2 > $OLDPWD/$OUT/pmcunet_$ctr.json 2>> $OLDPWD/$OUT/pmcunet_$ctr.log; rm -rf $OLDPWD/$OUT/pmcunet_$ctr; done) ;;
     normbench) (for g in ${GN_SWEEP:-2048}; do TC_GN_BLOCKS=$g timeout 120 python scripts/norm_bench.py 2>&1 | grep -v amdgpu.ids; done) > $OUT/norm_bench.log 2>&1 ;;
+    ordersweep) timeout 900 bash scripts/order_sweep.sh > $OUT/order_sweep.log 2>&1 ;;
     prof)   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o prof -- python $OLDPWD/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OLDPWD/$OUT/prof.log 2>&1; python $OLDPWD/scripts/prof_summary.py "$(find $OLDPWD/$OUT/prof -name '*.db' | head -1)" > $OLDPWD/$OUT/prof_stats.txt 2>> $OLDPWD/$OUT/prof.log; rm -rf $OLDPWD/$OUT/prof) ;;
     *) echo "unknown stage $s" ;;
   esac

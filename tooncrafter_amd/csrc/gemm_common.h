@@ -55,9 +55,9 @@ __device__ __forceinline__ void glds16(tc_rsrc_t rsrc, char* lds, uint32_t voff,
 // M-tile t always lives on XCD t & 7 and its A rows are fetched into one L2 only.  Within an XCD:
 //   order 0: all N-tiles of an M-tile back to back (A stays hot; W is re-streamed once per M-tile -- fine
 //            while the weight matrix fits the 4 MiB L2);
-//   order 1: N-tiles in chunks of 8: for each chunk, all M-tiles of the XCD, so ~64 co-resident blocks cover
-//            8 M-tiles x 8 N-tiles and both operands are re-read from L2, not from the fabric (for the wide-N
-//            layers whose W does not fit L2).
+//   order g > 0: N-tiles in chunks of g (8): for each chunk, all M-tiles of the XCD, so ~64 co-resident blocks
+//            cover 8 M-tiles x 8 N-tiles and both operands are re-read from L2, not from the fabric (for the
+//            wide-N layers whose W does not fit L2).
 // (Giving each XCD a CONTIGUOUS range of M-tiles instead -- so that 3x3 / temporal convolutions re-read their halo
 // rows from one L2 -- was measured 0.7 % slower on the UNet than this interleaved deal, and dropped.)
 __device__ __forceinline__ void tc_tile_of_block(int bid, int tiles_m, int tiles_n, int order, int& tile_m, int& tile_n) {
@@ -68,7 +68,7 @@ __device__ __forceinline__ void tc_tile_of_block(int bid, int tiles_m, int tiles
     tile_n = slot % tiles_n;
     return;
   }
-  constexpr int GN = 8;
+  const int GN = order;                                // N-tiles per chunk
   const int tm_x = (tiles_m + 7) >> 3;                 // M-tiles per XCD (upper bound; surplus blocks exit)
   const int full = (tiles_n / GN) * GN;
   int m_local;
@@ -86,8 +86,12 @@ __device__ __forceinline__ void tc_tile_of_block(int bid, int tiles_m, int tiles
 
 // host side: order 1 when the weight matrix outgrows one XCD's L2 and there are enough N-tiles to chunk
 inline int tc_gemm_tile_order(const TcGemmParams& p, int tiles_n) {
-  static const bool enabled = [] { const char* e = getenv("TC_GEMM_ORDER"); return !(e && e[0] == '0'); }();
-  return (enabled && tiles_n >= 16 && (int64_t)p.n * p.ldw * 2 > (4 << 20)) ? 1 : 0;
+  // TC_GEMM_ORDER = chunk width in N-tiles (default 8; 0 = always the plain walk); TC_GEMM_ORDER_MIB = weight
+  // size from which the chunked walk is used (default 4 = one XCD's L2)
+  static const int chunk = [] { const char* e = getenv("TC_GEMM_ORDER"); return e ? atoi(e) : 8; }();
+  static const int64_t min_bytes = [] { const char* e = getenv("TC_GEMM_ORDER_MIB");
+                                        return (int64_t)((e ? atof(e) : 4.0) * (1 << 20)); }();
+  return (chunk > 0 && tiles_n >= 2 * chunk && (int64_t)p.n * p.ldw * 2 > min_bytes) ? chunk : 0;
 }
 
 // Per-thread gather state for `R` rows of the A tile.
