@@ -215,55 +215,76 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __re
 }
 
 // ---------------------------------------------------------------------------------------
-// LayerNorm: one wave per row, row held in registers (<= 4 vectors of 8 per lane -> C <= 2048),
-// true two-pass variance.
-constexpr int LN_MAXV = 4;
+// LayerNorm: a wave normalises R rows at a time, each row held in registers (NV vectors of 8 per lane), true
+// two-pass variance.  R > 1 for the narrow rows (C <= 512: R = 4, C <= 1024: R = 2) puts several row loads in
+// flight per wave -- at C = 320 only 40 of the 64 lanes carry data, so one row per wave left the kernel
+// latency-bound (4.1 TB/s).
+template <int NV, int R>
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        int rows, int c, float eps) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (row0 >= rows) return;
   const int vpr = c >> 3;
-  const bf16_t* xr = x + (int64_t)row * c;
-  float f[LN_MAXV][8];
-  float s = 0.f;
+  float f[R][NV][8];
+  float s[R];
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    const int v = lane + i * 64;
-    if (v < vpr) {
-      unpack8(*reinterpret_cast<const u32x4*>(xr + v * 8), f[i]);
+  for (int r = 0; r < R; ++r) {
+    s[r] = 0.f;
+    const int row = min(row0 + r, rows - 1);                 // clamped rows are recomputed, never stored
+    const bf16_t* xr = x + (int64_t)row * c;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s += f[i][e];
+    for (int i = 0; i < NV; ++i) {
+      const int v = lane + i * 64;
+      u32x4 raw = {0u, 0u, 0u, 0u};
+      if (v < vpr) raw = *reinterpret_cast<const u32x4*>(xr + v * 8);
+      unpack8(raw, f[r][i]);
     }
   }
-  const float mean = wave_sum(s) / (float)c;
-  float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    const int v = lane + i * 64;
-    if (v < vpr) {
+  for (int r = 0; r < R; ++r) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { const float d = f[i][e] - mean; q += d * d; }
-    }
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[r] += f[r][i][e];        // lanes beyond the row hold zeros
   }
-  const float rstd = rsqrtf(wave_sum(q) / (float)c + eps);
-  bf16_t* yr = y + (int64_t)row * c;
+  float mean[R], rstd[R];
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int r = 0; r < R; ++r) mean[r] = wave_sum(s[r]) / (float)c;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = lane + i * 64;
+      if (v < vpr) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = f[r][i][e] - mean[r]; q += d * d; }
+      }
+    }
+    rstd[r] = rsqrtf(wave_sum(q) / (float)c + eps);
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
     const int v = lane + i * 64;
     if (v < vpr) {
-      float o[8];
       const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + v * 8);
       const f32x4 g1 = *reinterpret_cast<const f32x4*>(gamma + v * 8 + 4);
       const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + v * 8);
       const f32x4 b1 = *reinterpret_cast<const f32x4*>(beta + v * 8 + 4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        o[e] = (f[i][e] - mean) * rstd * g0[e] + b0[e];
-        o[4 + e] = (f[i][4 + e] - mean) * rstd * g1[e] + b1[e];
+      for (int r = 0; r < R; ++r) {
+        if (row0 + r < rows) {
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o[e] = (f[r][i][e] - mean[r]) * rstd[r] * g0[e] + b0[e];
+            o[4 + e] = (f[r][i][4 + e] - mean[r]) * rstd[r] * g1[e] + b1[e];
+          }
+          *reinterpret_cast<u32x4*>(y + (int64_t)(row0 + r) * c + v * 8) = pack8(o);
+        }
       }
-      *reinterpret_cast<u32x4*>(yr + v * 8) = pack8(o);
     }
   }
 }
@@ -346,10 +367,17 @@ extern "C" int tc_groupnorm(const tc_bf16* x, tc_bf16* y, const float* gamma, co
 extern "C" int tc_layernorm(const tc_bf16* x, tc_bf16* y, const float* gamma, const float* beta,
                             int32_t rows, int32_t c, float eps, void* stream) {
   if (!x || !y || !gamma || !beta || rows <= 0 || c <= 0) return TC_EINVAL;
-  if ((c % 8) != 0 || c > LN_MAXV * 64 * 8) return TC_ESHAPE;
+  if ((c % 8) != 0 || c > 4 * 64 * 8) return TC_ESHAPE;
   if (!tc_aligned16(x) || !tc_aligned16(y) || !tc_aligned16(gamma) || !tc_aligned16(beta)) return TC_EALIGN;
-  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     reinterpret_cast<const bf16_t*>(x), reinterpret_cast<bf16_t*>(y), gamma, beta, rows, c, eps);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const bf16_t* xb = reinterpret_cast<const bf16_t*>(x);
+  bf16_t* yb = reinterpret_cast<bf16_t*>(y);
+  if (c <= 512)
+    hipLaunchKernelGGL((layernorm_kernel<1, 4>), dim3((rows + 15) / 16), dim3(256), 0, st, xb, yb, gamma, beta, rows, c, eps);
+  else if (c <= 1024)
+    hipLaunchKernelGGL((layernorm_kernel<2, 2>), dim3((rows + 7) / 8), dim3(256), 0, st, xb, yb, gamma, beta, rows, c, eps);
+  else
+    hipLaunchKernelGGL((layernorm_kernel<4, 1>), dim3((rows + 3) / 4), dim3(256), 0, st, xb, yb, gamma, beta, rows, c, eps);
   TC_LAUNCH_CHECK();
   return TC_OK;
 }
