@@ -13,7 +13,9 @@
 //                 per-channel (scale, shift) registers and streams y = silu(x * scale + shift).
 // (Folding gn_finalize into gn_stats -- last block of a sample reduces, arrival counter + agent-scope
 // __threadfence() in every block -- was built and measured: the 2048 L2 write-back/invalidate fences
-// per launch cost far more than the 5 us launch they save, +27 % on the whole clip.  Three launches stay.)
+// per launch cost far more than the 5 us launch they save, +27 % on the whole clip.  Folding it into every
+// gn_apply block's prologue instead (partials re-reduced per block, no fences) measured neutral under hipGraph
+// replay.  Three launches stay.)
 // The chunk height is chosen on the host so that ~512 blocks are in flight whatever the
 // tensor shape (clip-wide statistics have only B samples, per-frame ones B*T).
 // Algorithmic traffic: read x twice, write y once (the second read mostly hits the 256 MiB
