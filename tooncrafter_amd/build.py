@@ -39,10 +39,19 @@ def _digest() -> str:
     return h.hexdigest()
 
 
+def _lib_digest_matches(dig: str) -> bool:
+    """The library carries the digest of the sources it was built from (tc_build_info): a stale .so next to
+    reverted or newer sources is detected whatever the file times say."""
+    try:
+        with open(LIB, "rb") as f:
+            return ("src:" + dig).encode() in f.read()
+    except OSError:
+        return False
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
-    stamp = LIB + ".stamp"
     dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+    if not force and _lib_digest_matches(dig):
         return LIB
     hipcc = _hipcc()
     objdir = os.path.join(HERE, "build")
@@ -52,7 +61,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for s in SOURCES:
         o = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(o)
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [hipcc, *FLAGS, f'-DTC_SRC_DIGEST="{dig}"', "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -65,8 +74,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    with open(stamp, "w") as f:
-        f.write(dig)
+    if not _lib_digest_matches(dig):
+        raise RuntimeError("built library does not carry the source digest")
     return LIB
 
 

@@ -315,4 +315,8 @@ extern "C" int tc_ddim_step(const TcDdimParams* pp, void* workspace, int64_t wor
 }
 
 extern "C" int tc_abi_version(void) { return TC_ABI_VERSION; }
-extern "C" const char* tc_build_info(void) { return "tooncrafter_hip gfx950 " __DATE__ " " __TIME__; }
+#ifndef TC_SRC_DIGEST
+#define TC_SRC_DIGEST "unknown"
+#endif
+// build.py looks for the "src:<digest>" marker in the binary to decide whether the library is current
+extern "C" const char* tc_build_info(void) { return "tooncrafter_hip gfx950 " __DATE__ " " __TIME__ " src:" TC_SRC_DIGEST; }
