@@ -363,8 +363,15 @@ def resampler_golden():
     x = torch.randn(2, 9, 96, generator=g)
     with torch.no_grad():
         y = m(x)
+    # ImageProjModel (resampler.py:9-23; unused by inference_512_v1.0.yaml, kept for checkpoints that use it)
+    ip = ref_rs.ImageProjModel(cross_attention_dim=64, clip_embeddings_dim=96, clip_extra_context_tokens=4).eval()
+    synth.fill_module_(ip, prefix="image_proj_model.", seed=1234)
+    xe = torch.randn(3, 96, generator=g)
+    with torch.no_grad():
+        ye = ip(xe)
     np.savez_compressed(os.path.join(HERE, "resampler_tiny.npz"), x=x.numpy(), y=y.numpy(),
-                        n_params=np.int64(sum(p.numel() for p in m.parameters())))
+                        n_params=np.int64(sum(p.numel() for p in m.parameters())),
+                        proj_x=xe.numpy(), proj_y=ye.numpy())
     full = dict(dim=1024, depth=4, dim_head=64, heads=12, num_queries=16, embedding_dim=1280, output_dim=1024,
                 ff_mult=4, video_length=16)
     with torch.device("meta"):

@@ -235,6 +235,20 @@ def test_resampler_host_logic(emu_fp32):
     assert rel_l2(y, torch.from_numpy(g["y"])) < 2e-2, rel_l2(y, torch.from_numpy(g["y"]))
 
 
+def test_image_proj_model_host_logic(emu_fp32):
+    """ImageProjModel (resampler.py:9-23) mirror against the reference class (tests/golden/resampler_tiny.npz)."""
+    from tooncrafter_amd import synth
+    from tooncrafter_amd.lvdm.resampler import ImageProjModel
+    g = load_golden("resampler_tiny.npz")
+    ip = ImageProjModel(cross_attention_dim=64, clip_embeddings_dim=96, clip_extra_context_tokens=4).eval()
+    assert set(ip.state_dict()) == {"proj.weight", "proj.bias", "norm.weight", "norm.bias"}
+    synth.fill_module_(ip, prefix="image_proj_model.", seed=1234)
+    with torch.no_grad():
+        y = ip(torch.from_numpy(g["proj_x"]))
+    assert y.shape == g["proj_y"].shape == (3, 4, 64)
+    assert rel_l2(y, torch.from_numpy(g["proj_y"])) < 1e-2
+
+
 def _tiny_towers():
     from tooncrafter_amd import synth
     from tooncrafter_amd.lvdm.openclip import CLIPText, VisionTransformer
