@@ -411,3 +411,15 @@ def test_encoder_tiny_host_logic(tiny_sd, emu_fp32):
         ref = torch.from_numpy(g[f"hid{i}"])
         assert h.shape == ref.shape
         assert rel_l2(h, ref) < 3e-2, i
+
+
+def test_conv_halo_model_design_artifact():
+    """scripts/conv_halo_model.py (the data movement planned for the tap-reuse 3x3 convolution):
+    exact against a direct convolution on a ragged image, and bank-conflict-free for every tap."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "conv_halo_model.py")
+    spec = importlib.util.spec_from_file_location("conv_halo_model", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    err, worst = mod.check(frames=1, H=9, W=35, C=64, N=8)
+    assert err < 1e-12 and worst == 0
