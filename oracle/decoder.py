@@ -126,14 +126,18 @@ def combiner(sd: SD, p: str, x: torch.Tensor, context: torch.Tensor) -> torch.Te
 
 
 def decoder_forward(sd: SD, z: torch.Tensor, ref_context: List[torch.Tensor], timesteps: int,
-                    num_levels: int = 4, num_res_blocks: int = 2) -> torch.Tensor:
-    """Decoder.forward with kwargs={'timesteps': T}.  z: (B*T, zc, h, w) already
+                    num_levels: int = 4, num_res_blocks: int = 2, probe=None) -> torch.Tensor:
+    """Decoder.forward with kwargs={'timesteps': T}.  `probe(name, tensor)`, when given, sees the activation
+    after the mid block and after every level's reference fusion (test instrumentation only).
+    z: (B*T, zc, h, w) already
     divided by scale_factor; ref_context: five (B, C, 2, H, W) tensors indexed by
     level (0 = full resolution) plus the final one.  -> (B*T, 3, 8h, 8w)."""
     h = _conv(sd, "conv_in", z, 1)
     h = video_res_block(sd, "mid.block_1", h, timesteps)
     h = mid_attention(sd, "mid.attn_1", h)
     h = video_res_block(sd, "mid.block_2", h, timesteps)
+    if probe is not None:
+        probe("mid", h)                                   # parity tests compare per stage: (B*T, C, H, W)
     for lvl in reversed(range(num_levels)):
         for ib in range(num_res_blocks + 1):
             h = video_res_block(sd, f"up.{lvl}.block.{ib}", h, timesteps)
@@ -142,6 +146,8 @@ def decoder_forward(sd: SD, z: torch.Tensor, ref_context: List[torch.Tensor], ti
             h = ref_fusion(sd, ar, h, ref_context[lvl])
         else:
             h = combiner(sd, ar, h, ref_context[lvl])
+        if probe is not None:
+            probe(f"level{lvl}", h)
         if lvl != 0:
             h = F.interpolate(h, scale_factor=2, mode="nearest")
             h = _conv(sd, f"up.{lvl}.upsample.conv", h, 1)

@@ -113,8 +113,45 @@ def load():
     ver = lib.tc_abi_version()
     if ver != TC_ABI_VERSION:
         raise TooncrafterHipError(f"ABI mismatch: library {ver}, binding {TC_ABI_VERSION}")
+    if os.environ.get("TC_DEBUG_SYNC"):
+        lib = _TracedLib(lib)
     _lib = lib
     return lib
+
+
+class _TracedLib:
+    """TC_DEBUG_SYNC=1: print every entry-point call (arguments, GEMM/attention parameter blocks) to stderr
+    BEFORE it runs and synchronise the device after it, so that a GPU memory fault -- which kills the
+    process asynchronously -- is attributable to the last line printed."""
+
+    def __init__(self, lib):
+        self._lib = lib
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if name not in SYMBOLS or name in ("tc_abi_version", "tc_build_info") or name.endswith("_workspace"):
+            return fn
+        import sys
+
+        import torch
+
+        def show(a):
+            s = getattr(a, "_obj", None)
+            if isinstance(s, C.Structure):
+                vals = []
+                for f, _ in s._fields_:
+                    v = getattr(s, f)
+                    vals.append("%s=%s" % (f, hex(v) if isinstance(v, int) and v > 1 << 20 else v))
+                return "{" + " ".join(vals) + "}"
+            return hex(a) if isinstance(a, int) and a > 1 << 20 else repr(a)
+
+        def traced(*args):
+            sys.stderr.write("[tc] %s %s\n" % (name, " ".join(show(a) for a in args)))
+            sys.stderr.flush()
+            rc = fn(*args)
+            torch.cuda.synchronize()
+            return rc
+        return traced
 
 
 def check(rc: int, what: str) -> None:

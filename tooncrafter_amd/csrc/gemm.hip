@@ -192,8 +192,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams pin, co
   if (tile_m >= tiles_m) return;
 
   const int64_t bz = blockIdx.z;
-  const tc_rsrc_t a_rsrc = make_rsrc(reinterpret_cast<const bf16_t*>(p.a) + bz * p.stride_a);
-  const tc_rsrc_t w_rsrc = make_rsrc(reinterpret_cast<const bf16_t*>(p.w) + bz * p.stride_w);
+  const tc_rsrc_t a_rsrc = make_rsrc(reinterpret_cast<const bf16_t*>(p.a) + bz * p.stride_a, tc_a_extent(p));
+  const tc_rsrc_t w_rsrc = make_rsrc(reinterpret_cast<const bf16_t*>(p.w) + bz * p.stride_w, tc_w_extent(p));
 
   // ---- loader geometry: thread -> (row lrow + 32 i, 16-byte chunk) of both tiles
   // The tile goes global -> LDS directly (buffer_load_dwordx4 ... lds).  One wave instruction fills

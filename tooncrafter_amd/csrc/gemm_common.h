@@ -29,14 +29,29 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // * rows that do not exist (M/N tails, convolution zero padding, K tails) get voffset = TC_OOB, which
 //   is >= num_records, so the hardware returns zeros: no masking instructions at all.
 // Valid offsets must stay below 2 GiB (checked on the host).
+// The descriptor's num_records is the TRUE byte extent of the operand (last row + its K columns), so a
+// mis-computed row / tap offset that leaves the operand reads zeros instead of whatever VA follows the
+// allocation (or faulting where nothing is mapped there); TC_OOB is >= any extent by construction.
 constexpr uint32_t TC_OOB = 0x80000000u;
 constexpr int TC_SRD_FLAGS = 0x00020000;
-constexpr int TC_SRD_RECORDS = 0x7ffffff0;
 
 typedef __amdgpu_buffer_rsrc_t tc_rsrc_t;
 
-__device__ __forceinline__ tc_rsrc_t make_rsrc(const void* base) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, TC_SRD_RECORDS, TC_SRD_FLAGS);
+__device__ __forceinline__ tc_rsrc_t make_rsrc(const void* base, int64_t bytes) {
+  const int rec = bytes < 0x7ffffff0LL ? (int)bytes : 0x7ffffff0;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, rec, TC_SRD_FLAGS);
+}
+
+// byte extents of one batch item of A (source rows of the gather) and W
+__host__ __device__ __forceinline__ int64_t tc_a_rows(const TcGemmParams& p) {
+  return p.gather == TC_GATHER_CONV3x3 ? (int64_t)p.frames * p.h_in * p.w_in : (int64_t)p.m;
+}
+__host__ __device__ __forceinline__ int64_t tc_a_extent(const TcGemmParams& p) {
+  const int kc = p.gather == TC_GATHER_LINEAR ? p.k : p.cin;
+  return ((tc_a_rows(p) - 1) * p.lda + kc) * 2;
+}
+__host__ __device__ __forceinline__ int64_t tc_w_extent(const TcGemmParams& p) {
+  return ((int64_t)(p.n - 1) * p.ldw + p.k) * 2;
 }
 
 __device__ __forceinline__ u32x4 buf_load16(tc_rsrc_t rsrc, uint32_t voff, uint32_t soff) {
@@ -179,9 +194,7 @@ struct AGather {
 // Host-side guard shared by the launchers: every byte offset a tile load can form must fit the
 // 31-bit range the out-of-range marker relies on.
 inline bool tc_gemm_offsets_fit(const TcGemmParams& p) {
-  int64_t a_rows = p.m;
-  if (p.gather == TC_GATHER_CONV3x3) a_rows = (int64_t)p.frames * p.h_in * p.w_in;
-  const int64_t a_bytes = a_rows * p.lda * 2;
+  const int64_t a_bytes = tc_a_rows(p) * p.lda * 2;
   const int64_t w_bytes = (int64_t)p.n * p.ldw * 2;
   return a_bytes < 0x7fffff00LL && w_bytes < 0x7fffff00LL;
 }

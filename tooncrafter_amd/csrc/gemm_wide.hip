@@ -46,8 +46,8 @@ __global__ __launch_bounds__(WTHREADS, 2) void gemm_wide_kernel(const TcGemmPara
   if (tile_m >= tiles_m) return;
 
   const int64_t bz = blockIdx.z;
-  const tc_rsrc_t a_rsrc = make_rsrc(reinterpret_cast<const bf16_t*>(p.a) + bz * p.stride_a);
-  const tc_rsrc_t w_rsrc = make_rsrc(reinterpret_cast<const bf16_t*>(p.w) + bz * p.stride_w);
+  const tc_rsrc_t a_rsrc = make_rsrc(reinterpret_cast<const bf16_t*>(p.a) + bz * p.stride_a, tc_a_extent(p));
+  const tc_rsrc_t w_rsrc = make_rsrc(reinterpret_cast<const bf16_t*>(p.w) + bz * p.stride_w, tc_w_extent(p));
 
   // tile loads go global -> LDS directly (buffer_load_dwordx4 ... lds, see gemm.hip): lane l of a wave
   // instruction lands at byte 16 l of a 1-KiB piece = (row l>>3, physical chunk l&7) of 8 tile rows, so

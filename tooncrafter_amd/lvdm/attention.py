@@ -23,7 +23,7 @@ import torch.nn as nn
 
 from .. import ops
 from .._lib import ACT_GEGLU
-from .common import Act, PackedModule, f32, pack_geglu, pack_linear
+from .common import Act, PackedModule, SourceKey, f32, pack_geglu, pack_linear
 
 
 class ContextCache:
@@ -57,9 +57,12 @@ class ContextCache:
         self.key = None
         self.refresh(context)
 
-    @staticmethod
-    def key_of(context: torch.Tensor):
-        return (context.data_ptr(), context._version)
+    def is_current(self, context: torch.Tensor) -> bool:
+        """True when the cache was filled from this very tensor object at its current version."""
+        return self.key is not None and self.key.same([context])
+
+    def invalidate(self):
+        self.key = None
 
     def matches(self, context: torch.Tensor, t: int) -> bool:
         return self.shape == tuple(context.shape) and self.t == t and self.text_rows.device == context.device
@@ -73,7 +76,7 @@ class ContextCache:
             self.img_rows.copy_(ctx[:, self.text_len:].reshape(-1, cc))
         for module, kv_text, kv_img in self.kv.values():
             module.project_context(self, kv_text, kv_img)
-        self.key = self.key_of(context)
+        self.key = SourceKey([context])
 
 
 class GEGLU(nn.Module):

@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .common import Act, PackedModule, ceil_to, f32, pack_conv3x3, pack_convt3, pack_linear
+from .common import Act, PackedModule, SourceKey, ceil_to, f32, pack_conv3x3, pack_convt3, pack_linear
 from .openaimodel3d import Upsample, _conv_geom
 
 
@@ -136,7 +136,7 @@ class RefContext:
     `[B*2*H*W, C]` (row = (b*2 + l)*HW + p) and reusable across decode calls."""
 
     def __init__(self, ref_context: List[torch.Tensor]):
-        self.key = tuple((r.data_ptr(), r._version, tuple(r.shape)) for r in ref_context)
+        self.key = SourceKey(ref_context)      # strong references + versions: never data_ptr identity
         self.rows = []
         self.geom = []
         for r in ref_context:
@@ -271,14 +271,18 @@ class VideoDecoder(PackedModule):
         return self
 
     def ref_cache(self, ref_context) -> RefContext:
-        key = tuple((r.data_ptr(), r._version, tuple(r.shape)) for r in ref_context)
-        if self._ref_cache is None or self._ref_cache.key != key:
+        if self._ref_cache is None or not self._ref_cache.key.same(ref_context):
             self._ref_cache = RefContext(ref_context)
         return self._ref_cache
 
-    def decode_clip(self, z, ref_context, scale=1.0):
+    def reset_conditioning(self):
+        """Clip boundary: drop the cached reference rows / K/V."""
+        self._ref_cache = None
+
+    def decode_clip(self, z, ref_context, scale=1.0, probe=None):
         """z: (B, zc, T, h, w) fp32 latent -> (B, 3, T, 8h, 8w) fp32.  `scale` multiplies z on the
-        way in (decode_core's 1/scale_factor)."""
+        way in (decode_core's 1/scale_factor).  `probe(name, act)` (parity tests only) sees the
+        activation after the mid block and after each level's reference fusion."""
         b, zc, t, h, w = z.shape
         pk = self.pk
         ref = self.ref_cache(ref_context) if ref_context else None
@@ -289,11 +293,15 @@ class VideoDecoder(PackedModule):
         act = self.mid.block_1(act)
         act = self.mid.attn_1(act)
         act = self.mid.block_2(act)
+        if probe is not None:
+            probe("mid", act)
         for lvl in reversed(range(self.num_resolutions)):
             for blk in self.up[lvl].block:
                 act = blk(act)
             if ref is not None:
                 act = self.attn_refinement[lvl](act, ref, lvl)
+            if probe is not None:
+                probe(f"level{lvl}", act)
             if lvl != 0:
                 act = self.up[lvl].upsample(act)
         hrows = ops.groupnorm(act.rows, pk["og"], pk["ob"], samples=act.frames, rows=act.hw, eps=1e-6, silu=True)

@@ -40,6 +40,26 @@ class Act:
         return Act(rows, self.b, self.t, self.h if h is None else h, self.w if w is None else w)
 
 
+class SourceKey:
+    """Identity of the tensors a cache was filled from.  Holds STRONG references, so the caching
+    allocator cannot recycle their storage under a new tensor while the cache lives, and compares by
+    object identity + version counter -- never by `data_ptr()`, which a freed-and-reallocated tensor of
+    the next clip can share (round-1 bug: clip 2 silently sampled with clip 1's conditioning)."""
+
+    def __init__(self, tensors):
+        self.tensors = list(tensors)
+        self.versions = [None if t is None else t._version for t in self.tensors]
+
+    def same(self, tensors) -> bool:
+        tensors = list(tensors)
+        if len(tensors) != len(self.tensors):
+            return False
+        for a, b, v in zip(self.tensors, tensors, self.versions):
+            if a is not b or (a is not None and a._version != v):
+                return False
+        return True
+
+
 # --------------------------------------------------------------------------- packers
 def f32(t: torch.Tensor) -> torch.Tensor:
     return t.detach().to(torch.float32).contiguous()

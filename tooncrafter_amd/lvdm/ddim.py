@@ -99,6 +99,8 @@ class DDIMSampler(object):
                 print(f"Warning: Got {cbs} conditionings but batch-size is {batch_size}")
         self.make_schedule(ddim_num_steps=S, ddim_discretize=timestep_spacing, ddim_eta=eta,
                            verbose=schedule_verbose)
+        if hasattr(self.model, "reset_conditioning"):
+            self.model.reset_conditioning()          # a sampling run = one clip: never reuse cached conditioning
         if len(shape) == 3:
             size = (batch_size, *shape)
         else:
@@ -170,12 +172,15 @@ class DDIMSampler(object):
             e_c = self.model.apply_model(x, t, c, **kwargs)
             e_u = self.model.apply_model(x, t, unconditional_conditioning, **kwargs)
         sc = self.step_scalars(index, step)
-        noise = None
+        # the reference draws the noise every step, also when sigma == 0 (ddim.py:266): draw (and drop) it so
+        # the device generator stays in step with the reference for later draws (x_T of the next variant)
+        noise = noise_like(x.shape, x.device, repeat_noise)
         if sc["sigma"] != 0.0:
-            noise = noise_like(x.shape, x.device, repeat_noise)
             if temperature != 1.:
                 noise = noise * temperature
             noise = noise.to(torch.float32).contiguous()
+        else:
+            noise = None
         x_prev, pred_x0 = ops.ddim_step(x.contiguous(), e_c.contiguous(), None if e_u is None else e_u.contiguous(),
                                         noise, cfg_scale=unconditional_guidance_scale,
                                         guidance_rescale=guidance_rescale if use_cfg else 0.0, **sc)

@@ -47,12 +47,13 @@ class DDIMSampler(_DDIMSampler):
             e_u = self.model.apply_model(x, t, unconditional_conditioning, **kwargs)
             e_i = self.model.apply_model(x, t, uc_img, **kwargs)
         sc = self.step_scalars(index, step)
-        noise = None
+        noise = _ddim.noise_like(x.shape, x.device, repeat_noise)     # always drawn, like the reference (:277)
         if sc["sigma"] != 0.0:
-            noise = _ddim.noise_like(x.shape, x.device, repeat_noise)
             if temperature != 1.:
                 noise = noise * temperature
             noise = noise.to(torch.float32).contiguous()
+        else:
+            noise = None
         cont = lambda v: None if v is None else v.contiguous()
         return ops.ddim_step(x.contiguous(), e_c.contiguous(), cont(e_u), noise,
                              cfg_scale=unconditional_guidance_scale,

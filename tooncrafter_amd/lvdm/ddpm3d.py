@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from ..utils import instantiate_from_config
+from .common import SourceKey
 from .utils_diffusion import make_beta_schedule, rescale_zero_terminal_snr
 
 
@@ -219,12 +220,13 @@ class LatentDiffusion(DDPM):
             return [self.apply_model(x_noisy, t, c, **kwargs) for c in conds]
         b = x_noisy.shape[0]
         fs = kwargs.get("fs")
-        cond_t = [tns for c in conds for tns in (*c["c_crossattn"], *c["c_concat"])]
-        sig = (n,) + tuple((c.data_ptr(), c._version, tuple(c.shape)) for c in cond_t) + (
-            None if fs is None else (fs.data_ptr(), fs._version), tuple(x_noisy.shape), x_noisy.device)
+        # identity of the conditioning: the tensor OBJECTS (strong references held by SourceKey) and their
+        # versions -- never data_ptr(), which the next clip's freshly allocated tensors can share
+        cond_t = [tns for c in conds for tns in (*c["c_crossattn"], *c["c_concat"])] + [fs]
+        shape_sig = (n, tuple(x_noisy.shape), x_noisy.device)
         st = self._cfg_state
         unet = self.model.diffusion_model
-        if st is None or st["sig"] != sig:
+        if st is None or st["key"] is None or st["shape_sig"] != shape_sig or not st["key"].same(cond_t):
             # conditioning changed (new clip): (re)fill the static batch-nB inputs; same-shape buffers are
             # reused so that a captured graph stays valid
             cat = lambda key: torch.cat([torch.cat(c[key], 1) for c in conds], dim=0)
@@ -242,7 +244,7 @@ class LatentDiffusion(DDPM):
                     ctx2=ctx2.contiguous(), cc2=cc2.contiguous(), fs2=fs2,
                     x2=torch.empty((n * b, *x_noisy.shape[1:]), dtype=torch.float32, device=x_noisy.device),
                     ts2=torch.empty((n * b,), dtype=torch.long, device=x_noisy.device), graph=None, calls=0)
-            st["sig"] = sig
+            st["key"], st["shape_sig"] = SourceKey(cond_t), shape_sig
             unet.context_cache(st["ctx2"], x_noisy.shape[2])          # project K/V now (in place if cached)
         for k in range(n):
             st["x2"][k * b:(k + 1) * b].copy_(x_noisy)
@@ -266,6 +268,17 @@ class LatentDiffusion(DDPM):
             out = fwd()
         st["calls"] += 1
         return [out[k * b:(k + 1) * b] for k in range(n)]
+
+    def reset_conditioning(self):
+        """Clip boundary (called by the samplers at the start of `sample()`, like one iteration of the
+        prompt loop of scripts/evaluation/inference.py:324-342): whatever tensors carry the next
+        conditioning, the static batch-nB inputs and every cached K/V projection are re-filled IN PLACE on
+        the next guided step (same buffers, so a captured hipGraph stays valid)."""
+        if self._cfg_state is not None:
+            self._cfg_state["key"] = None
+        unet = self.model.diffusion_model
+        if hasattr(unet, "reset_conditioning"):
+            unet.reset_conditioning()
 
     @torch.no_grad()
     def decode_first_stage(self, z, **kwargs):

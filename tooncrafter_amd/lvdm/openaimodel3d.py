@@ -314,9 +314,14 @@ class UNetModel(PackedModule):
         c = self._ctx_cache
         if c is None or not c.matches(context, t):
             c = self._ctx_cache = ContextCache(context, t)
-        elif c.key != ContextCache.key_of(context):
+        elif not c.is_current(context):
             c.refresh(context)
         return c
+
+    def reset_conditioning(self):
+        """Clip boundary: the next forward re-reads the conditioning whatever tensor carries it."""
+        if self._ctx_cache is not None:
+            self._ctx_cache.invalidate()
 
     def _embedding(self, timesteps, fs, b):
         """silu(time_embed(t) + fps_embedding(fs)) pushed through every ResBlock's emb Linear:

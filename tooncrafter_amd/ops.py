@@ -44,6 +44,21 @@ def _rows_view(t: torch.Tensor, dtype=BF16):
     return t
 
 
+def _dev(t: Optional[torch.Tensor], dtype, what: str, contiguous: bool = True):
+    """Pointer of a device operand, or raise: a CPU pointer handed to a kernel faults the GPU (and kills
+    the process) instead of raising, so every tensor whose data_ptr() crosses the C ABI is checked here."""
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.TooncrafterHipError(f"{what}: expected a CUDA tensor, got "
+                                       f"{getattr(t, 'device', type(t))}: the product path is GPU-only")
+    if t.dtype != dtype:
+        raise ValueError(f"{what}: expected {dtype}, got {t.dtype}")
+    if contiguous and not t.is_contiguous():
+        raise ValueError(f"{what}: must be contiguous")
+    return t.data_ptr()
+
+
 class HipOps:
     """The product backend: ctypes calls into libtooncrafter_hip.so."""
 
@@ -71,6 +86,7 @@ class HipOps:
         a = _rows_view(a)
         if w.dtype != BF16 or w.dim() != 2 or w.stride(1) != 1:
             raise ValueError("w must be a [N, K] bf16 tensor with unit column stride")
+        _dev(w, BF16, "gemm: w", contiguous=False)
         n, k = w.shape
         n_out = n // 2 if act == ACT_GEGLU else n
         p = TcGemmParams()
@@ -94,6 +110,8 @@ class HipOps:
             need_rows = p.frames * p.h_in * p.w_in
             if a.shape[0] < need_rows:
                 raise ValueError(f"conv source has {a.shape[0]} rows, geometry needs {need_rows}")
+            if a.shape[1] < p.cin or k != (9 if kind == "3x3" else 3) * p.cin:
+                raise ValueError(f"conv source has {a.shape[1]} channels / weight K = {k}, geometry says cin = {p.cin}")
         if out is None:
             out = torch.empty((mm, n_out), dtype=torch.float32 if out_f32 else BF16, device=a.device)
         else:
@@ -102,16 +120,16 @@ class HipOps:
                 raise ValueError(f"out shape {tuple(out.shape)} != ({mm}, {n_out})")
         p.a, p.w, p.c = a.data_ptr(), w.data_ptr(), out.data_ptr()
         if bias is not None:
-            if bias.dtype != torch.float32 or bias.numel() != n:
+            if bias.numel() != n:
                 raise ValueError("bias must be fp32 [N]")
-            p.bias = bias.data_ptr()
+            p.bias = _dev(bias, torch.float32, "gemm: bias")
         if row_bias is not None:
             if row_bias.dtype != torch.float32 or row_bias.dim() != 2 or row_bias.stride(1) != 1 \
                     or row_bias.shape[1] != n:
                 raise ValueError("row_bias must be fp32 [R, N] with unit column stride")
             if row_div <= 0 or row_bias.shape[0] * row_div < mm:
                 raise ValueError("row_bias / row_div do not cover M")
-            p.row_bias = row_bias.data_ptr()
+            p.row_bias = _dev(row_bias, torch.float32, "gemm: row_bias", contiguous=False)
             p.ldrb = row_bias.stride(0)
         if residual is not None:
             _rows_view(residual)
@@ -180,10 +198,13 @@ class HipOps:
         c = x.shape[1]
         if not x.is_contiguous() or x.shape[0] != samples * rows:
             raise ValueError("groupnorm: x must be contiguous [samples*rows, C]")
+        if gamma.numel() != c or beta.numel() != c:
+            raise ValueError("groupnorm: gamma/beta must have C elements")
+        gp, bp = _dev(gamma, torch.float32, "groupnorm: gamma"), _dev(beta, torch.float32, "groupnorm: beta")
         y = torch.empty_like(x)
         nbytes = self.lib.tc_groupnorm_workspace(samples, rows, c)
         ws = self._workspace(nbytes, x.device)
-        _lib.check(self.lib.tc_groupnorm(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), samples,
+        _lib.check(self.lib.tc_groupnorm(x.data_ptr(), y.data_ptr(), gp, bp, samples,
                                          rows, c, float(eps), 1 if silu else 0, ws.data_ptr(), nbytes, _stream()),
                    "tc_groupnorm")
         return y
@@ -192,8 +213,11 @@ class HipOps:
         x = _rows_view(x)
         if not x.is_contiguous():
             raise ValueError("layernorm: x must be contiguous")
+        if gamma.numel() != x.shape[1] or beta.numel() != x.shape[1]:
+            raise ValueError("layernorm: gamma/beta must have C elements")
+        gp, bp = _dev(gamma, torch.float32, "layernorm: gamma"), _dev(beta, torch.float32, "layernorm: beta")
         y = torch.empty_like(x)
-        _lib.check(self.lib.tc_layernorm(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+        _lib.check(self.lib.tc_layernorm(x.data_ptr(), y.data_ptr(), gp, bp,
                                          x.shape[0], x.shape[1], float(eps), _stream()), "tc_layernorm")
         return y
 
@@ -220,7 +244,7 @@ class HipOps:
         c1 = 0
         if x1 is not None:
             x1 = x1.contiguous()
-            if x1.dtype != torch.float32 or x1.shape[0] != b or tuple(x1.shape[2:]) != (t, h, w):
+            if not x1.is_cuda or x1.dtype != torch.float32 or x1.shape[0] != b or tuple(x1.shape[2:]) != (t, h, w):
                 raise ValueError("nchw_to_rows: second tensor shape mismatch")
             c1 = x1.shape[1]
         out = torch.empty((b * t * h * w, c_pad), dtype=BF16, device=x0.device)
@@ -268,8 +292,11 @@ class HipOps:
         """rows: fp32 [b*t*h*w_, ld>=3]; w: fp32 [3,3,3,1,1]; -> (b, 3, t, h, w_) fp32."""
         if rows.dtype != torch.float32 or rows.dim() != 2 or rows.stride(1) != 1 or not rows.is_cuda:
             raise ValueError("time_mix3: fp32 CUDA rows")
+        if w.numel() != 27 or bias.numel() != 3:
+            raise ValueError("time_mix3: w must have 27 elements, bias 3")
+        wp, bp = _dev(w, torch.float32, "time_mix3: w"), _dev(bias, torch.float32, "time_mix3: bias")
         out = torch.empty((b, 3, t, h, w_), dtype=torch.float32, device=rows.device)
-        _lib.check(self.lib.tc_time_mix3(rows.data_ptr(), rows.stride(0), w.data_ptr(), bias.data_ptr(),
+        _lib.check(self.lib.tc_time_mix3(rows.data_ptr(), rows.stride(0), wp, bp,
                                          out.data_ptr(), b, t, h * w_, _stream()), "tc_time_mix3")
         return out
 
