@@ -13,11 +13,21 @@ HBM when the timed region starts.  Clips shard over ranks with no data-path coll
 rank 0 gathers the decoded clips once at the end of every step (RCCL).  Weights are
 synthetic (tooncrafter_amd/synth.py), generated on the device.
 
+Every step runs a DIFFERENT clip (two resident input sets alternate), so the per-clip refresh of the
+static CFG inputs, of the cross-attention K/V and of the decoder's reference K/V is inside the timed region.
+
+`--gpus N` with N > 1 and no torchrun environment: this script launches its own N ranks
+(python -m torch.distributed.run, 127.0.0.1) -- `python bench.py --gpus 8` works without a wrapper.
+`--batched-decode B` measures BASELINE.json configs[3] (perframe_ae=False): B clips per GPU whose B*T frames
+go through ONE decoder call (the only B>1-correct geometry of the dual-reference fusion).
+
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
   roofline     : bf16 MFMA GEMM/implicit-conv kernel -- sum(algorithmic FLOP)/sum(duration) over
                  every launch of one B=2 UNet forward, HIP events on the launch stream;
-  cpu_baseline : the CPU oracle (oracle/unet.py, fp32) timed on ONE full-size UNet forward
-                 on this host, scaled to frames/s by the clip's algorithmic FLOPs.
+  roofline_hbm : the GroupNorm(+SiLU) operator (HBM-bound): algorithmic bytes (2 B read + 2 B written per
+                 element) / duration over every launch of the same forward;
+  cpu_baseline : the CPU oracle (oracle/, fp32) timed on this host on a bounded sample -- ONE full-size UNet
+                 forward and a 4-frame decode -- scaled to one clip by the unit counts (100 forwards, 30 frames).
 """
 import argparse
 import json
@@ -101,19 +111,33 @@ def make_inputs(device, seed):
     return d
 
 
+STAGE_EVENTS = []      # [(name, start, end)] HIP events of the timed steps: where a clip's time goes
+
+
+def _mark():
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
 def run_clip(model, sampler, inp, ddim_steps):
     """scripts/evaluation/inference.py:244-270, from resident conditioning to the decoded clip."""
     cond = {"c_crossattn": [inp["cond"]], "c_concat": [inp["c_concat"]]}
     uc = {"c_crossattn": [inp["uncond"]], "c_concat": [inp["c_concat"]]}
+    e0 = _mark()
     samples, _ = sampler.sample(S=ddim_steps, conditioning=cond, batch_size=1, shape=(4, 16, 40, 64), verbose=False,
                                 unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=1.0,
                                 cfg_img=None, mask=None, x0=None, fs=inp["fs"], timestep_spacing="uniform_trailing",
                                 guidance_rescale=0.7, x_T=inp["x_T"], unconditional_conditioning_img_nonetext=None)
+    e1 = _mark()
     video = model.decode_first_stage(samples, ref_context=inp["refs"])
+    e2 = _mark()
     idx = [i for i in range(samples.shape[2]) if i not in (1, samples.shape[2] - 2)]
     video2 = model.decode_first_stage(samples[:, :, idx].contiguous(), ref_context=inp["refs"])
     mid = video2.shape[2] // 2
     video[:, :, 7:9] = video2[:, :, mid - 1:mid + 1]          # splice the two middle frames (inference.py:268-270)
+    e3 = _mark()
+    STAGE_EVENTS.extend([("ddim_sampler", e0, e1), ("decode_16f", e1, e2), ("decode_14f_splice", e2, e3)])
     return video
 
 
@@ -147,6 +171,57 @@ class GemmProbe:
         ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.rec)
         fl = sum(f for _, _, f in self.rec)
         return len(self.rec), ms, fl
+
+
+class NormProbe:
+    """Brackets every tc_groupnorm call (its three launches) with HIP events; algorithmic bytes = 2 B read +
+    2 B written per element."""
+
+    def __init__(self, backend):
+        self.b, self.orig, self.rec = backend, backend.groupnorm, []
+
+    def __enter__(self):
+        def groupnorm(x, *a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = self.orig(x, *a, **kw)
+            e1.record()
+            self.rec.append((e0, e1, 4.0 * x.numel()))
+            return out
+        self.b.groupnorm = groupnorm
+        return self
+
+    def __exit__(self, *a):
+        self.b.groupnorm = self.orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        return len(self.rec), sum(e0.elapsed_time(e1) for e0, e1, _ in self.rec), sum(f for _, _, f in self.rec)
+
+
+PEAK_HBM_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def measure_roofline_hbm(model, inp):
+    un = model.model.diffusion_model
+    x2, cc2 = torch.cat([inp["x_T"]] * 2), torch.cat([inp["c_concat"]] * 2)
+    ctx2 = torch.cat([inp["cond"], inp["uncond"]])
+    ts = torch.full((2,), 499, device=x2.device, dtype=torch.long)
+    fs2 = torch.cat([inp["fs"]] * 2)
+    with torch.no_grad():
+        un(None, ts, context=ctx2, fs=fs2, x_parts=[x2, cc2])
+        torch.cuda.synchronize()
+        big = torch.empty((8192, 8192), device=x2.device, dtype=torch.bfloat16).normal_()
+        for _ in range(6):
+            big @ big
+        with NormProbe(ops.backend()) as probe:
+            un(None, ts, context=ctx2, fs=fs2, x_parts=[x2, cc2])
+        n, ms, by = probe.summary()
+    gbs = by / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "tc_groupnorm (GroupNorm32 + SiLU over channels-last rows)",
+            "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+            "traffic": None, "launches": n, "avg_launch_us": round(ms * 1e3 / max(n, 1), 2),
+            "algorithmic_gb_per_unet_fwd_b2": round(by / 1e9, 3), "ms_per_unet_fwd_b2": round(ms, 3)}
 
 
 def measure_roofline(model, inp):
@@ -199,14 +274,81 @@ def cpu_baseline(model, inp):
         y = ounet.unet_forward(sd, UNET_CFG, x, ts, inp["cond"].cpu(), inp["fs"].cpu())
         t_fwd = time.time() - t1
         yg = un(x.to(inp["x_T"].device), ts.to(inp["x_T"].device), context=inp["cond"], fs=inp["fs"])
+        # decoder sample: 4 of the clip's frames at full resolution (cost is linear in frames)
+        from oracle import decoder as odec
+        dec = model.first_stage_model.decoder
+        dsd = {k: v.detach().float().cpu() for k, v in dec.state_dict().items()}
+        z4 = torch.randn(1, 4, 4, 40, 64, generator=torch.Generator().manual_seed(11))
+        refs_cpu = [r.cpu() for r in inp["refs"]]
+        t2 = time.time()
+        d = odec.decode_first_stage(dsd, z4, refs_cpu)
+        t_dec4 = time.time() - t2
+        dg = dec.decode_clip(z4.to(inp["x_T"].device), inp["refs"], scale=1.0 / 0.18215)
     rel = float((yg.double().cpu() - y.double()).norm() / y.double().norm())
-    clip_s = t_fwd * TFLOP_CLIP / TFLOP_UNET_FWD
+    rel_dec = float((dg.double().cpu() - d.double()).norm() / d.double().norm())
+    clip_s = 100.0 * t_fwd + (16 + 14) / 4.0 * t_dec4
     return {"value": round(16.0 / clip_s, 6), "unit": "frames/s", "cores": torch.get_num_threads(),
             "host_cpus": os.cpu_count(), "kind": "port",
-            "sample": f"1 full-size UNet forward (B=1, 12.603 TFLOP) of the fp32 CPU oracle: {t_fwd:.1f} s; "
-                      f"scaled by {TFLOP_CLIP:.1f}/{TFLOP_UNET_FWD} TFLOP to one DDIM-50 clip",
-            "unet_fwd_s": round(t_fwd, 2), "parity_rel_l2_hip_vs_oracle_full_size": round(rel, 5),
-            "prep_s": round(t1 - t0, 1)}
+            "sample": f"fp32 CPU oracle: 1 full-size UNet forward (B=1, 12.603 TFLOP) {t_fwd:.1f} s + a 4-frame "
+                      f"full-resolution decode {t_dec4:.1f} s; one clip = 100 forwards + (16+14)/4 such decodes",
+            "unet_fwd_s": round(t_fwd, 2), "decode_4f_s": round(t_dec4, 2),
+            "parity_rel_l2_hip_vs_oracle_full_size": round(rel, 5),
+            "parity_rel_l2_hip_vs_oracle_decode_4f": round(rel_dec, 5), "prep_s": round(t1 - t0, 1)}
+
+
+def run_clips_batched_decode(model, sampler, inps, ddim_steps):
+    """BASELINE.json configs[3] (perframe_ae=False): B clips sampled one after the other (batch 1, the scripts
+    assert bs == 1, inference.py:296), then ALL B*T frames through ONE decoder call with timesteps=T --
+    the call the reference crashes on (ddpm3d.py:656-657) and the only geometry in which the dual-reference
+    fusion indexes its per-clip K/V correctly for B > 1."""
+    lat = []
+    for inp in inps:
+        cond = {"c_crossattn": [inp["cond"]], "c_concat": [inp["c_concat"]]}
+        uc = {"c_crossattn": [inp["uncond"]], "c_concat": [inp["c_concat"]]}
+        s, _ = sampler.sample(S=ddim_steps, conditioning=cond, batch_size=1, shape=(4, 16, 40, 64), verbose=False,
+                              unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=1.0, fs=inp["fs"],
+                              timestep_spacing="uniform_trailing", guidance_rescale=0.7, x_T=inp["x_T"])
+        lat.append(s)
+    samples = torch.cat(lat, 0)
+    refs = inps[0]["refs_batched"]
+    video = model.decode_first_stage(samples, ref_context=refs)
+    idx = [i for i in range(samples.shape[2]) if i not in (1, samples.shape[2] - 2)]
+    video2 = model.decode_first_stage(samples[:, :, idx].contiguous(), ref_context=refs)
+    mid = video2.shape[2] // 2
+    video[:, :, 7:9] = video2[:, :, mid - 1:mid + 1]
+    return video
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks ourselves, one process per GPU over
+    RCCL on 127.0.0.1 (the analogue of the reference's scripts/evaluation/ddp_wrapper.py:29-47)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def launcher_selftest(args):
+    """CPU check of the launcher + rendezvous + gather plumbing (tests/test_dist_cpu.py): every rank
+    contributes one small 'clip', rank 0 gathers and prints the JSON line.  No GPU, gloo backend."""
+    from tooncrafter_amd import dist as tcdist
+    rank, world = tcdist.init(backend="gloo")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    clip = torch.full((1, 3, 2, 4, 4), float(rank))
+    got = tcdist.gather_clips(clip, dst=0)
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"selftest": "launcher", "n_gpus": world,
+                          "gathered": [float(g.mean()) for g in got]}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -215,9 +357,17 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--batched-decode", type=int, default=0, metavar="B",
+                    help="configs[3]: B clips per GPU per step, decoded in one call (perframe_ae=False)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    if args.launcher_selftest:
+        return launcher_selftest(args)
 
     from tooncrafter_amd import dist as tcdist
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -230,12 +380,26 @@ def main():
     from tooncrafter_amd.lvdm.ddim import DDIMSampler
     model = build_model(device)
     sampler = DDIMSampler(model)
-    inp = make_inputs(device, seed=7 + rank)
-    gather_buf = [torch.empty((1, 3, 16, 320, 512), device=device) for _ in range(world)] if rank == 0 and world > 1 else None
+    bdec = args.batched_decode
+    clips_per_step = bdec if bdec > 0 else 1
+    # two resident input sets per rank: consecutive steps run DIFFERENT clips (per-clip refresh is timed)
+    n_sets = 2 * clips_per_step
+    inps = [make_inputs(device, seed=7 + rank + 1000 * j) for j in range(n_sets)]
+    if bdec > 0:
+        for j in (0, bdec):
+            inps[j]["refs_batched"] = [torch.cat([inps[j + i]["refs"][l] for i in range(bdec)], 0) for l in range(5)]
+    shape = (clips_per_step, 3, 16, 320, 512)
+    gather_buf = [torch.empty(shape, device=device) for _ in range(world)] if rank == 0 and world > 1 else None
+    counter = [0]
 
     def step():
+        k = counter[0] % 2
+        counter[0] += 1
         with torch.no_grad():
-            video = run_clip(model, sampler, inp, args.ddim_steps)
+            if bdec > 0:
+                video = run_clips_batched_decode(model, sampler, inps[k * bdec:(k + 1) * bdec], args.ddim_steps)
+            else:
+                video = run_clip(model, sampler, inps[k], args.ddim_steps)
             tcdist.gather_clips(video, dst=0, out=gather_buf)       # the one collective of the path
         return video
 
@@ -248,6 +412,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    STAGE_EVENTS.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         video = step()
@@ -261,21 +426,29 @@ def main():
 
     result = None
     if rank == 0:
-        frames = 16 * args.steps * world
+        frames = 16 * args.steps * world * clips_per_step
         result = {
             "metric": "interpolated frames/sec, 512x320x16f DDIM-50", "value": round(frames / dt, 4),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "ToonCrafter_512 320x512x16f ddim_steps=%d CFG 7.5 bf16, 1 clip per GPU "
-                                   "(BASELINE.json configs[1]); sampler + 16f decode + 14f re-decode + splice"
-                                   % args.ddim_steps,
-                       "clips_per_step": world, "parallelism": f"dp{world} (independent clips, one RCCL gather)"},
-            "effective_tflops_per_gpu": round(TFLOP_CLIP * args.steps / dt, 1) if args.ddim_steps == 50 else None,
-            "mfma_fraction_whole_clip": round(TFLOP_CLIP * args.steps / dt / PEAK_BF16_TFLOPS, 4)
+            "config": {"workload": ("ToonCrafter_512 320x512x16f ddim_steps=%d CFG 7.5 bf16, %s; sampler + 16f decode "
+                                    "+ 14f re-decode + splice; a different clip every step") % (
+                                        args.ddim_steps,
+                                        "1 clip per GPU (BASELINE.json configs[1])" if bdec == 0 else
+                                        f"{bdec} clips per GPU decoded in one call, perframe_ae=False (BASELINE.json configs[3])"),
+                       "clips_per_step": world * clips_per_step,
+                       "parallelism": f"dp{world} (independent clips, one RCCL gather)"},
+            "effective_tflops_per_gpu": round(TFLOP_CLIP * args.steps * clips_per_step / dt, 1) if args.ddim_steps == 50 else None,
+            "mfma_fraction_whole_clip": round(TFLOP_CLIP * args.steps * clips_per_step / dt / PEAK_BF16_TFLOPS, 4)
             if args.ddim_steps == 50 else None,
             "output_finite": finite,
         }
+        if STAGE_EVENTS:
+            acc = {}
+            for name, a, b in STAGE_EVENTS:
+                acc[name] = acc.get(name, 0.0) + a.elapsed_time(b)
+            result["stage_ms_per_clip"] = {k: round(v / args.steps, 2) for k, v in acc.items()}
     if rank == 0:
         # row f1 (not part of `value`): the first-stage encoder that produces z and the reference
         # hidden states, 16 frames at 320x512, reported so that "with encoder" can be derived
@@ -288,11 +461,12 @@ def main():
             torch.cuda.synchronize()
         enc_ms = (time.perf_counter() - te) * 1e3
         result["encoder_16f_ms"] = round(enc_ms, 2)
-        result["frames_per_s_with_encoder"] = round(16.0 / (dt / args.steps + enc_ms * 1e-3), 4)
+        result["frames_per_s_with_encoder"] = round(16.0 / (dt / args.steps / clips_per_step + enc_ms * 1e-3), 4)
     if rank == 0 and not args.no_roofline:
-        result["roofline"] = measure_roofline(model, inp)
+        result["roofline"] = measure_roofline(model, inps[0])
+        result["roofline_hbm"] = measure_roofline_hbm(model, inps[0])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(model, inp)
+        result["cpu_baseline"] = cpu_baseline(model, inps[0])
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -123,7 +123,7 @@ def ddim_step(x: torch.Tensor, e_cond: torch.Tensor, e_uncond: Optional[torch.Te
     s1 = buffers["sqrt_one_minus_alphas_cumprod"][t]
     e_t = sa * out + s1 * x
     pred_x0 = sa * x - s1 * out
-    full = lambda v: torch.full(size, float(v), dtype=torch.float32)
+    full = lambda v: torch.full(size, float(v), dtype=torch.float32, device=x.device)
     a_prev = full(tab["alphas_prev"][index])
     sigma_t = full(tab["sigmas"][index])
     if "scale_arr" in tab:
@@ -150,7 +150,7 @@ def ddim_sample(apply_model: Callable, x_T: torch.Tensor, cond, uncond, S: int, 
     b = x_T.shape[0]
     for i, step in enumerate(np.flip(tab["timesteps"])):
         index = S - i - 1
-        ts = torch.full((b,), int(step), dtype=torch.long)
+        ts = torch.full((b,), int(step), dtype=torch.long, device=x_T.device)
         e_c = apply_model(img, ts, cond)
         e_u = apply_model(img, ts, uncond) if (uncond is not None and cfg_scale != 1.0) else None
         e_i = apply_model(img, ts, uncond_img) if (e_u is not None and uncond_img is not None) else None

@@ -32,7 +32,7 @@ SD = Dict[str, torch.Tensor]
 def timestep_embedding(t: torch.Tensor, dim: int, max_period: float = 10000.0) -> torch.Tensor:
     """utils_diffusion.py:19-23: [cos(t f_i) | sin(t f_i)], f_i = exp(-ln(P) i / half)."""
     half = dim // 2
-    freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32) / half)
+    freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
     args = t[:, None].float() * freqs[None]
     emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
     if dim % 2:
@@ -224,7 +224,7 @@ def unet_forward(sd: SD, cfg: dict, x: torch.Tensor, timesteps: torch.Tensor,
     h = x.permute(0, 2, 1, 3, 4).reshape(b * t, x.shape[1], x.shape[3], x.shape[4])
     if "fps_embedding.0.weight" in sd:
         if fs is None:
-            fs = torch.full((b,), cfg.get("default_fs", 4), dtype=torch.long)
+            fs = torch.full((b,), cfg.get("default_fs", 4), dtype=torch.long, device=x.device)
         fe = _lin(sd, "fps_embedding.2", F.silu(_lin(sd, "fps_embedding.0", timestep_embedding(fs, mc))))
         emb = emb + fe.repeat_interleave(t, dim=0)
     h = h.float()

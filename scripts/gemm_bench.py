@@ -48,7 +48,7 @@ def conv(frames, h, w, cin, cout, tag="", t3=False, tlen=16):
     print(f"{'convT3 ' if t3 else 'conv3x3'} {tag:14s} f={frames:3d} {h}x{w} {cin}->{cout}  {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF/s")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--attn-only" not in sys.argv:
     print(hip.lib.tc_build_info().decode())
     lin(81920, 320, 320, res=True, tag="L0 proj")
     lin(81920, 960, 320, tag="L0 qkv")
@@ -106,6 +106,7 @@ def attn(batch, heads, lq, lk, kv_bdiv=1, tag=""):
 if __name__ == "__main__":
     attn(32, 5, 2560, 2560, tag="L0 self")
     attn(32, 10, 640, 640, tag="L1 self")
+    attn(32, 20, 160, 160, tag="L2 self")
     attn(32, 5, 2560, 77, 16, tag="L0 text")
     attn(32, 5, 2560, 16, 1, tag="L0 image")
     attn(16, 8, 10240, 20480, 16, tag="dec L2 ref")

@@ -153,13 +153,16 @@ class EmuOps:
         return self._out(out)
 
     # ------------------------------------------------------------------ layout / elementwise
-    def nchw_to_rows(self, x0, x1=None, *, c_pad, scale=1.0):
+    def nchw_to_rows(self, x0, x1=None, *, c_pad, scale=1.0, out=None):
         x = x0 if x1 is None else torch.cat([x0, x1], dim=1)
         b, c, t, h, w = x.shape
         rows = (x * scale).permute(0, 2, 3, 4, 1).reshape(b * t * h * w, c)
-        out = torch.zeros((rows.shape[0], c_pad), dtype=torch.float32, device=x.device)
-        out[:, :c] = rows
-        return out.to(BF16)
+        full = torch.zeros((rows.shape[0], c_pad), dtype=torch.float32, device=x.device)
+        full[:, :c] = rows
+        if out is not None:
+            out.copy_(full.to(BF16))
+            return out
+        return full.to(BF16)
 
     def rows_to_nchw(self, rows, *, c, b, t, h, w):
         return _f(rows[:, :c]).reshape(b, t, h, w, c).permute(0, 4, 1, 2, 3).contiguous()

@@ -50,8 +50,32 @@ def _worker(rank, world, port, ret):
     else:
         assert got is None
         ret.put((True, mine))
+    # ragged shards (5 clips over 2 ranks = 3 + 2): padded gather, one collective per rank, exact counts back
+    mine_clips = torch.stack([torch.full((3, 2, 4, 4), float(i)) for i in mine]) if mine else torch.empty((0, 3, 2, 4, 4))
+    rag = gather_clips(mine_clips, dst=0, ragged=True)
+    if rank == 0:
+        flat = [int(c[0, 0, 0, 0]) for part in rag for c in part]
+        assert [len(p) for p in rag] == [len(shard_indices(5, world, r)) for r in range(world)] and flat == list(range(5))
+    else:
+        assert rag is None
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` outside torchrun starts two ranks itself (torch.distributed.run on 127.0.0.1);
+    checked on CPU with the launcher self-test leg (gloo): rendezvous, gather to rank 0, ONE JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launcher-selftest"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    assert json.loads(lines[0]) == {"selftest": "launcher", "n_gpus": 2, "gathered": [0.0, 1.0]}
 
 
 def test_gather_world2_gloo():

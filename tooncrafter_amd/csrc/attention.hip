@@ -11,7 +11,9 @@
 //
 // attn_temporal_kernel: 16-frame (or shorter) self-attention at every pixel; the whole
 // problem is 16x16x64 per (pixel, head), done on the VALU by one wave.
-#include "common.h"
+#include "gemm_common.h"
+
+#include <stdlib.h>
 
 namespace {
 
@@ -197,6 +199,207 @@ __global__ __launch_bounds__(256) void attn_d64_kernel(const TcAttnParams p) {
 }
 
 // ---------------------------------------------------------------------------------------
+// attn_d64_dma_kernel: same mathematics and register-level dataflow as attn_d64_kernel (swapped S^T = K Q^T, in-lane
+// softmax, P fed back as the B operand of O^T += V^T P^T), different STAGING:
+//   * K and V tiles travel global -> LDS directly (buffer_load_dwordx4 ... lds, 1 KiB pieces, out-of-range keys
+//     zero-filled by the buffer bounds check) into a double-buffered image: the loads of tile t+1 are issued right
+//     after the single barrier of tile t and land under its MFMAs -- no staging registers, no ds_write pass (the
+//     register path spent 18 LDS stores per thread per tile, 16 of them 2-byte transposing stores), one barrier
+//     per tile instead of two;
+//   * V stays ROW-major [key][d] in LDS and the V^T fragments of the PV product are read with
+//     ds_read_b64_tr_b16 (hardware 4x4 transpose: a 16-lane group reads a [4 keys][16 d] block, every lane
+//     gets the 4 keys of its own d column);
+//   * both images are XOR-swizzled on the SOURCE side of the DMA (the LDS destination of a DMA piece is
+//     lane-linear): K chunks by (row>>1)&7 (conflict-free ds_read_b128 of 16 different rows), V chunks by
+//     ((row>>1)&1)<<2 (the four key rows of a transposing read land in four different bank quarters).
+constexpr int KD_TILE = KT * 128;            // 8 KiB: 64 keys x 64 d bf16, 128-byte rows
+constexpr int DMA_STAGE = 2 * KD_TILE;       // K + V of one tile
+
+__device__ __forceinline__ u32x2 lds_read_tr16_b64(const char* p) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+  return __builtin_bit_cast(u32x2, v);
+}
+
+__global__ __launch_bounds__(256) void attn_d64_dma_kernel(const TcAttnParams p) {
+  __shared__ __attribute__((aligned(1024))) char smem[2 * DMA_STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int kvb = b / p.kv_bdiv;
+  const bf16_t* qb = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.q_sb + h * 64;
+  const bf16_t* kb = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)kvb * p.k_sb + h * 64;
+  const bf16_t* vb = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)kvb * p.v_sb + h * 64;
+  bf16_t* ob = reinterpret_cast<bf16_t*>(p.o) + (int64_t)b * p.o_sb + h * 64;
+  // descriptors over exactly the lk rows of this (batch, head): a key row >= lk is out of range and reads as zeros
+  const tc_rsrc_t k_rsrc = make_rsrc(kb, ((int64_t)(p.lk - 1) * p.k_ss + 64) * 2);
+  const tc_rsrc_t v_rsrc = make_rsrc(vb, ((int64_t)(p.lk - 1) * p.v_ss + 64) * 2);
+
+  const int q_row = blockIdx.x * 128 + wave * 32 + l31;
+  const int q_ld = q_row < p.lq ? q_row : p.lq - 1;   // clamp: tail rows compute garbage, never stored
+  bf16x8 qf[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+    qf[kk] = *reinterpret_cast<const bf16x8*>(qb + (int64_t)q_ld * p.q_ss + kk * 16 + half * 8);
+
+  // ---- DMA geometry: a tile is 8 pieces of 8 key rows per matrix; wave w issues pieces w and w + 4.  Lane l of a
+  // piece lands at (row l>>3, physical chunk l&7) and therefore FETCHES the logical chunk whose swizzled home that is.
+  const int prow = lane >> 3;
+  uint32_t k_voff[2], v_voff[2];
+  int piece_row[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave + 4 * i) * 8 + prow;                  // key row inside the tile
+    piece_row[i] = row;
+    const int kchunk = (lane & 7) ^ ((row >> 1) & 7);
+    const int vchunk = (lane & 7) ^ (((row >> 1) & 1) << 2);
+    k_voff[i] = (uint32_t)(row * p.k_ss * 2 + kchunk * 16);
+    v_voff[i] = (uint32_t)(row * p.v_ss * 2 + vchunk * 16);
+  }
+  auto dma_tile = [&](int kt, int stage) {
+    const int key0 = kt * KT;
+    char* sk = smem + stage * DMA_STAGE + wave_u * 1024;
+    char* sv = sk + KD_TILE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const uint32_t dead = (key0 + piece_row[i] < p.lk) ? 0u : TC_OOB;      // ragged last tile: zero rows
+      glds16(k_rsrc, sk + i * 4096, k_voff[i] | dead, (uint32_t)key0 * (uint32_t)p.k_ss * 2u);
+      glds16(v_rsrc, sv + i * 4096, v_voff[i] | dead, (uint32_t)key0 * (uint32_t)p.v_ss * 2u);
+    }
+  };
+
+  // ---- fragment read offsets (per lane, fixed for the whole kernel)
+  // K (A operand of S^T = K Q^T): lane (key l31 of block kbk, k = 16 kk + 8 half ..): 16-byte chunk 2 kk + half of its row
+  int k_off[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) k_off[kk] = l31 * 128 + (((kk * 2 + half) ^ ((l31 >> 1) & 7)) << 4);
+  // V (A operand of O^T += V^T P^T through the transposing read): 16-lane group g = lane>>4 serves the d columns
+  // 16 (g&1) .. +15 of d-block d0 with key sub-block 4 half; lane i of the group addresses row i>>2, d 4 (i&3) .. +3
+  const int lg = lane & 15;
+  int v_off[2];
+#pragma unroll
+  for (int d0 = 0; d0 < 2; ++d0) {
+    const int vrow = lg >> 2;                                   // + key0 (multiple of 4): swizzle bit = (vrow>>1)&1
+    const int col = d0 * 32 + 16 * ((lane >> 4) & 1) + 4 * (lg & 3);
+    const int chunk = (col >> 3) ^ (((vrow >> 1) & 1) << 2);
+    v_off[d0] = vrow * 128 + chunk * 16 + (col & 7) * 2;
+  }
+
+  const float c = p.scale * 1.4426950408889634f;   // softmax in base 2
+  float m_run = -1e30f, l_run = 0.f;
+  f32x16 oacc[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+
+  const int n_tiles = (p.lk + KT - 1) / KT;
+  dma_tile(0, 0);
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    const int key0 = kt * KT;
+    // tile kt has landed for this wave (vmcnt) and for every wave (barrier); the same barrier retires all reads
+    // of the buffer the next DMA overwrites
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < n_tiles) dma_tile(kt + 1, (kt + 1) & 1);
+    const char* ks = smem + (kt & 1) * DMA_STAGE;
+    const char* vs = ks + KD_TILE;
+
+    f32x16 st[2];
+#pragma unroll
+    for (int kbk = 0; kbk < 2; ++kbk) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[kbk][r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + kbk * 32 * 128 + k_off[kk]);
+        st[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st[kbk], 0, 0, 0);
+      }
+    }
+    if (key0 + KT > p.lk) {
+#pragma unroll
+      for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key0 + kbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          st[kbk][r] = key < p.lk ? st[kbk][r] : -1e30f;
+        }
+    }
+    float mx = st[0][0];
+#pragma unroll
+    for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kbk][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx * c);
+    if (!__all(m_new == m_run)) {
+      const float alpha = exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+      m_run = m_new;
+    }
+    float rs = 0.f;
+#pragma unroll
+    for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = exp2f(fmaf(st[kbk][r], c, -m_run));
+        st[kbk][r] = pv;
+        rs += pv;
+      }
+    rs += __shfl_xor(rs, 32, 64);
+    l_run += rs;
+
+    // O^T += V^T P^T: k-slot (half, j) of slab s in key block kbk carries key kbk*32 + 16 s + 8 (j>>2) + 4 half + (j&3)
+    // for both operands; the V side is two transposing reads (keys +0..3 and +8..11 of the slab) per fragment
+#pragma unroll
+    for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)st[kbk][8 * s + j];
+        const int kbase = (kbk * 32 + 16 * s + 4 * half) * 128;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const u32x2 lo = lds_read_tr16_b64(vs + kbase + v_off[d]);
+          const u32x2 hi = lds_read_tr16_b64(vs + kbase + 8 * 128 + v_off[d]);
+          u32x4 vv = {lo[0], lo[1], hi[0], hi[1]};
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, oacc[d], 0, 0, 0);
+        }
+      }
+  }
+
+  if (q_row < p.lq) {
+    const float inv = 1.0f / l_run;
+    bf16_t* orow = ob + (int64_t)q_row * p.o_ss;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dim = d * 32 + 8 * g + 4 * half;
+        float x0 = oacc[d][4 * g + 0] * inv, x1 = oacc[d][4 * g + 1] * inv;
+        float x2 = oacc[d][4 * g + 2] * inv, x3 = oacc[d][4 * g + 3] * inv;
+        u32x2* dst = reinterpret_cast<u32x2*>(orow + dim);
+        if (p.accumulate) {
+          const u32x2 old = *dst;
+          x0 += __uint_as_float(old[0] << 16);
+          x1 += __uint_as_float(old[0] & 0xffff0000u);
+          x2 += __uint_as_float(old[1] << 16);
+          x3 += __uint_as_float(old[1] & 0xffff0000u);
+        }
+        u32x2 out = {pack2(x0, x1), pack2(x2, x3)};
+        *dst = out;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Temporal attention: one wave per (batch b, pixel p, head h).  Lane = (query i = lane/4,
 // quarter = lane%4 owning 16 of the 64 dims).  K and V of the sequence sit in LDS as fp32.
 __global__ __launch_bounds__(256) void attn_temporal_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
@@ -293,7 +496,14 @@ extern "C" int tc_attn_d64(const TcAttnParams* pp, void* stream) {
   if ((p.q_sb & 7) || (p.k_sb & 7) || (p.v_sb & 7) || (p.o_sb & 7)) return TC_EALIGN;
   if (p.heads > 65535 || p.batch > 65535) return TC_ESHAPE;
   dim3 grid((p.lq + 127) / 128, p.heads, p.batch), block(256);
-  hipLaunchKernelGGL(attn_d64_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream), p);
+  // TC_ATTN_STAGE=reg selects the register-staged kernel (A/B runs); the DMA-staged one needs 31-bit row offsets
+  static const bool use_reg = [] { const char* e = getenv("TC_ATTN_STAGE"); return e && e[0] == 'r'; }();
+  const bool fits = (int64_t)p.lk * p.k_ss * 2 < 0x7fffff00LL && (int64_t)p.lk * p.v_ss * 2 < 0x7fffff00LL &&
+                    p.k_ss >= 64 && p.v_ss >= 64;
+  if (!use_reg && fits)
+    hipLaunchKernelGGL(attn_d64_dma_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream), p);
+  else
+    hipLaunchKernelGGL(attn_d64_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream), p);
   TC_LAUNCH_CHECK();
   return TC_OK;
 }

@@ -41,13 +41,36 @@ def init(backend: Optional[str] = None, device: Optional[torch.device] = None) -
     return rank, world
 
 
-def gather_clips(video: torch.Tensor, dst: int = 0, out: Optional[List[torch.Tensor]] = None):
+def gather_clips(video: torch.Tensor, dst: int = 0, out: Optional[List[torch.Tensor]] = None,
+                 ragged: bool = False):
     """Gather every rank's decoded clip(s) `(b, 3, T, H, W)` to `dst`.  Returns the list of
-    per-rank tensors on `dst` (rank order), None elsewhere.  World size 1: [video]."""
+    per-rank tensors on `dst` (rank order), None elsewhere.  World size 1: [video].
+
+    `dist.gather` needs the SAME shape -- and the same number of collective calls -- on every rank.  With
+    `shard_indices` spreading a remainder, ranks own different clip counts `b`: pass `ragged=True` and every rank
+    is padded to the largest count (one extra all_gather of the counts), the padding cut off again on `dst`.
+    Every rank must call this exactly once per step, also a rank that owns no clip (b = 0)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [video]
     rank, world = dist.get_rank(), dist.get_world_size()
     video = video.contiguous()
+    if ragged:
+        cnt = torch.tensor([video.shape[0]], dtype=torch.int64, device=video.device)
+        cnts = [torch.empty_like(cnt) for _ in range(world)]
+        dist.all_gather(cnts, cnt)
+        counts = [int(c.item()) for c in cnts]
+        mx = max(counts)
+        if mx == 0:
+            return [video[:0] for _ in range(world)] if rank == dst else None
+        if video.shape[0] < mx:
+            pad = torch.zeros((mx - video.shape[0], *video.shape[1:]), dtype=video.dtype, device=video.device)
+            video = torch.cat([video, pad], 0)
+        if rank == dst:
+            bufs = [torch.empty_like(video) for _ in range(world)]
+            dist.gather(video, bufs, dst=dst)
+            return [b[:c] for b, c in zip(bufs, counts)]
+        dist.gather(video, None, dst=dst)
+        return None
     if rank == dst:
         if out is None:
             out = [torch.empty_like(video) for _ in range(world)]

@@ -18,6 +18,7 @@ Result-preserving restructurings:
 """
 from __future__ import annotations
 
+import os
 from typing import List
 
 import torch
@@ -132,20 +133,35 @@ class MemoryEfficientAttnBlock(PackedModule):
 
 
 class RefContext:
-    """The five encoder hidden states of the first/last frame, converted once to bf16 rows
-    `[B*2*H*W, C]` (row = (b*2 + l)*HW + p) and reusable across decode calls."""
+    """The five encoder hidden states of the first/last frame as bf16 rows `[B*2*H*W, C]`
+    (row = (b*2 + l)*HW + p), plus the fusion blocks' projected K/V, reusable across decode calls.
+    A new clip with the same geometry REFRESHES the buffers in place, so captured hipGraphs of the
+    decoder keep pointing at valid data (same scheme as attention.ContextCache)."""
 
     def __init__(self, ref_context: List[torch.Tensor]):
-        self.key = SourceKey(ref_context)      # strong references + versions: never data_ptr identity
         self.rows = []
         self.geom = []
         for r in ref_context:
             b, c, l, h, w = r.shape
             if l != 2:
                 raise ValueError("ref_context tensors must be (B, C, 2, H, W)")
-            self.rows.append(ops.nchw_to_rows(r.float(), c_pad=c))
+            self.rows.append(torch.empty((b * l * h * w, c), dtype=torch.bfloat16, device=r.device))
             self.geom.append((b, c, h, w))
-        self.kv = {}
+        self.kv = {}           # id(module) -> (module, level, kv buffer)
+        self.key = None
+        self.refresh(ref_context)
+
+    def matches(self, ref_context) -> bool:
+        return len(ref_context) == len(self.geom) and all(
+            tuple(r.shape) == (b, c, 2, h, w) and r.device == rows.device
+            for r, (b, c, h, w), rows in zip(ref_context, self.geom, self.rows))
+
+    def refresh(self, ref_context):
+        for r, rows in zip(ref_context, self.rows):
+            ops.nchw_to_rows(r.detach().float(), c_pad=r.shape[1], out=rows)
+        for module, level, kv in self.kv.values():
+            module.project_ref(self, level, kv)
+        self.key = SourceKey(ref_context)      # strong references + versions: never data_ptr identity
 
 
 class MemoryEfficientCrossAttentionWrapperFusion(PackedModule):
@@ -167,12 +183,16 @@ class MemoryEfficientCrossAttentionWrapperFusion(PackedModule):
                 "wkv": pack_linear(torch.cat([self.to_k.weight, self.to_v.weight], 0)),
                 "wo": pack_linear(self.to_out[0].weight), "bo": f32(self.to_out[0].bias)}
 
+    def project_ref(self, ref: RefContext, level: int, out=None):
+        return ops.gemm(ref.rows[level], self.pk["wkv"], out=out)               # [B*2*HW, 2*inner], once per clip
+
     def forward(self, act: Act, ref: RefContext, level: int) -> Act:
         pk = self.pk
         inner = self.heads * 64
-        kv = ref.kv.get(id(self))
-        if kv is None:
-            kv = ref.kv[id(self)] = ops.gemm(ref.rows[level], pk["wkv"])     # [B*2*HW, 2*inner], once per clip
+        hit = ref.kv.get(id(self))
+        if hit is None:
+            hit = ref.kv[id(self)] = (self, level, self.project_ref(ref, level))
+        kv = hit[2]
         hn = ops.groupnorm(act.rows, pk["g"], pk["b"], samples=act.frames, rows=act.hw, eps=1e-6)
         q = ops.gemm(hn, pk["wq"])
         a = ops.attention(q, kv[:, :inner], kv[:, inner:], batch=act.frames, heads=self.heads, lq=act.hw,
@@ -257,6 +277,8 @@ class VideoDecoder(PackedModule):
         self.attn_refinement.append(Combiner(block_in))
         self.conv_out = AE3DConv(block_in, out_ch, video_kernel_size=video_kernel_size, kernel_size=3, stride=1, padding=1)
         self._ref_cache = None
+        self._graphs = {}          # (z shape, scale, with refs) -> static input/output + captured hipGraph
+        self.use_hipgraph = os.environ.get("TC_HIPGRAPH", "1") != "0"
 
     def _pack(self):
         return {"wi": pack_conv3x3(self.conv_in.weight), "bi": f32(self.conv_in.bias),
@@ -271,21 +293,56 @@ class VideoDecoder(PackedModule):
         return self
 
     def ref_cache(self, ref_context) -> RefContext:
-        if self._ref_cache is None or not self._ref_cache.key.same(ref_context):
-            self._ref_cache = RefContext(ref_context)
-        return self._ref_cache
+        c = self._ref_cache
+        if c is None or not c.matches(ref_context):
+            c = self._ref_cache = RefContext(ref_context)
+            self._graphs.clear()                       # captured graphs point at the old buffers
+        elif c.key is None or not c.key.same(ref_context):
+            c.refresh(ref_context)                     # new clip, same geometry: in place
+        return c
 
     def reset_conditioning(self):
-        """Clip boundary: drop the cached reference rows / K/V."""
+        """Clip boundary: the next decode re-reads the reference features whatever tensors carry them."""
+        if self._ref_cache is not None:
+            self._ref_cache.key = None
+
+    def _apply(self, fn, recurse=True):               # .to(device): static buffers and graphs are stale
         self._ref_cache = None
+        self._graphs = {}
+        return super()._apply(fn, recurse)
 
     def decode_clip(self, z, ref_context, scale=1.0, probe=None):
         """z: (B, zc, T, h, w) fp32 latent -> (B, 3, T, 8h, 8w) fp32.  `scale` multiplies z on the
         way in (decode_core's 1/scale_factor).  `probe(name, act)` (parity tests only) sees the
-        activation after the mid block and after each level's reference fusion."""
+        activation after the mid block and after each level's reference fusion.
+
+        The ~1000 launches of one decode are captured in a hipGraph per (latent shape, scale) the second
+        time that geometry is decoded and replayed afterwards (static input/output buffers; the reference
+        rows and K/V are refreshed in place per clip) -- at ~17 us of ctypes host time per eager launch the
+        host, not the GPU, would otherwise pace the decoder."""
+        ref = self.ref_cache(ref_context) if ref_context else None
+        if not (self.use_hipgraph and z.is_cuda and probe is None and ops.backend().name == "hip"):
+            return self._decode(z, ref, scale, probe)
+        key = (tuple(z.shape), float(scale), ref is not None)
+        st = self._graphs.get(key)
+        if st is None:
+            st = self._graphs[key] = {"z": torch.empty(z.shape, dtype=torch.float32, device=z.device),
+                                      "graph": None, "out": None, "calls": 0}
+        st["z"].copy_(z)
+        st["calls"] += 1
+        if st["graph"] is None:
+            if st["calls"] < 2:                        # first decode of this geometry runs eagerly (packs, K/V)
+                return self._decode(st["z"], ref, scale, None)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                st["out"] = self._decode(st["z"], ref, scale, None)
+            st["graph"] = g
+        st["graph"].replay()
+        return st["out"].clone()
+
+    def _decode(self, z, ref, scale, probe):
         b, zc, t, h, w = z.shape
         pk = self.pk
-        ref = self.ref_cache(ref_context) if ref_context else None
         cpad = ceil_to(zc, 64)
         act = Act(ops.nchw_to_rows(z.float(), c_pad=cpad, scale=scale), b, t, h, w)
         geom, _, _ = _conv_geom(act, cpad)

@@ -279,6 +279,9 @@ class LatentDiffusion(DDPM):
         unet = self.model.diffusion_model
         if hasattr(unet, "reset_conditioning"):
             unet.reset_conditioning()
+        dec = getattr(self.first_stage_model, "decoder", None)
+        if hasattr(dec, "reset_conditioning"):
+            dec.reset_conditioning()
 
     @torch.no_grad()
     def decode_first_stage(self, z, **kwargs):

@@ -235,8 +235,8 @@ class HipOps:
         return p
 
     # ------------------------------------------------------------------ layout / elementwise
-    def nchw_to_rows(self, x0, x1=None, *, c_pad, scale=1.0):
-        """(B, C0, T, H, W) [+ (B, C1, T, H, W)] fp32 -> bf16 rows [(b t h w), c_pad]."""
+    def nchw_to_rows(self, x0, x1=None, *, c_pad, scale=1.0, out=None):
+        """(B, C0, T, H, W) [+ (B, C1, T, H, W)] fp32 -> bf16 rows [(b t h w), c_pad] (into `out` when given)."""
         if x0.dtype != torch.float32 or x0.dim() != 5 or not x0.is_cuda:
             raise ValueError("nchw_to_rows: fp32 CUDA (B, C, T, H, W)")
         x0 = x0.contiguous()
@@ -247,7 +247,10 @@ class HipOps:
             if not x1.is_cuda or x1.dtype != torch.float32 or x1.shape[0] != b or tuple(x1.shape[2:]) != (t, h, w):
                 raise ValueError("nchw_to_rows: second tensor shape mismatch")
             c1 = x1.shape[1]
-        out = torch.empty((b * t * h * w, c_pad), dtype=BF16, device=x0.device)
+        if out is None:
+            out = torch.empty((b * t * h * w, c_pad), dtype=BF16, device=x0.device)
+        elif not out.is_contiguous() or _rows_view(out).shape != (b * t * h * w, c_pad):
+            raise ValueError("nchw_to_rows: out must be a contiguous [(b t h w), c_pad] bf16 tensor")
         _lib.check(self.lib.tc_nchw_to_rows(x0.data_ptr(), c0, _ptr(x1), c1, out.data_ptr(), c_pad, b, t, h * w,
                                             float(scale), _stream()), "tc_nchw_to_rows")
         return out
