@@ -103,6 +103,100 @@ def _install_shims() -> None:
         m.seed_everything = seed_everything
         m.LightningModule = torch.nn.Module
         sys.modules["pytorch_lightning"] = m
+    if missing("torchvision"):
+        _install_torchvision_shim()
+
+
+def _install_torchvision_shim() -> None:
+    """The slice of torchvision the reference's inference script touches (inference.py:9-10,65-69,126-133,
+    154-155): PIL-based Resize / CenterCrop / ToTensor / Normalize / Compose, utils.make_grid and io.write_video.
+    No video encoder exists on such an image, so write_video stores the uint8 frames as `.npy` next to the
+    path the `.mp4` would have had (the same fallback as tooncrafter_amd.output.default_writer)."""
+    import os
+
+    import numpy as np
+    import torch
+    from PIL import Image
+
+    tv = types.ModuleType("torchvision")
+    tv.__path__ = []
+    tv.__tooncrafter_shim__ = True
+    tr = types.ModuleType("torchvision.transforms")
+
+    class Compose:
+        def __init__(self, transforms):
+            self.transforms = list(transforms)
+
+        def __call__(self, x):
+            for t in self.transforms:
+                x = t(x)
+            return x
+
+    class Resize:
+        """int size: the SHORTER side becomes `size`, aspect kept (torchvision semantics); bilinear + antialias."""
+
+        def __init__(self, size, interpolation=None, **kw):
+            self.size = size
+
+        def __call__(self, img):
+            w, h = img.size
+            if isinstance(self.size, int):
+                if (w <= h and w == self.size) or (h <= w and h == self.size):
+                    return img
+                if w < h:
+                    ow, oh = self.size, int(self.size * h / w)
+                else:
+                    oh, ow = self.size, int(self.size * w / h)
+            else:
+                oh, ow = self.size
+            return img.resize((ow, oh), Image.BILINEAR)
+
+    class CenterCrop:
+        def __init__(self, size):
+            self.size = (size, size) if isinstance(size, int) else tuple(size)
+
+        def __call__(self, img):
+            w, h = img.size
+            th, tw = self.size
+            left, top = int(round((w - tw) / 2.0)), int(round((h - th) / 2.0))
+            return img.crop((left, top, left + tw, top + th))
+
+    class ToTensor:
+        def __call__(self, img):
+            a = np.asarray(img, dtype=np.uint8)
+            if a.ndim == 2:
+                a = a[:, :, None]
+            return torch.from_numpy(a.copy()).permute(2, 0, 1).to(torch.float32).div(255.0)
+
+    class Normalize:
+        def __init__(self, mean, std, inplace=False):
+            self.mean, self.std = torch.tensor(mean).view(-1, 1, 1), torch.tensor(std).view(-1, 1, 1)
+
+        def __call__(self, x):
+            return (x - self.mean) / self.std
+
+    tr.Compose, tr.Resize, tr.CenterCrop, tr.ToTensor, tr.Normalize = Compose, Resize, CenterCrop, ToTensor, Normalize
+    ut = types.ModuleType("torchvision.utils")
+
+    def make_grid(tensor, nrow=8, padding=2, **kw):
+        if padding != 0:
+            raise NotImplementedError("shim make_grid: padding=0 only (what the scripts use)")
+        t = tensor if tensor.dim() == 4 else tensor.unsqueeze(0)
+        rows = [torch.cat(list(t[i:i + nrow]), dim=2) for i in range(0, t.shape[0], nrow)]
+        return torch.cat(rows, dim=1)
+
+    ut.make_grid = make_grid
+    io = types.ModuleType("torchvision.io")
+
+    def write_video(filename, video_array, fps, video_codec="h264", options=None, **kw):
+        alt = os.path.splitext(filename)[0] + ".npy"
+        os.makedirs(os.path.dirname(alt) or ".", exist_ok=True)
+        np.save(alt, torch.as_tensor(video_array).cpu().numpy())
+        return alt
+
+    io.write_video = write_video
+    tv.transforms, tv.utils, tv.io = tr, ut, io
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tr, "torchvision.utils": ut, "torchvision.io": io})
 
 
 def main(argv=None):

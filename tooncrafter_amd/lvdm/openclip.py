@@ -189,3 +189,15 @@ class _VisualHolder(nn.Module):
         v = a["vision"]
         self.visual = VisionTransformer(v["width"], v["layers"], v["heads"], v["patch"], v["image"], v["mlp"],
                                         a["embed_dim"])
+        # The reference deletes only `model.transformer` (condition.py:309): the rest of open_clip's CLIP text half
+        # stays in the module -- and therefore in every ToonCrafter checkpoint (`embedder.model.positional_embedding`,
+        # `text_projection`, `logit_scale`, `token_embedding.weight`, `ln_final.*`).  Dead weights, but
+        # `load_state_dict(strict=True)` (inference.py:32,44) needs a home for each of them.
+        t = a["text"]
+        self.positional_embedding = nn.Parameter(torch.zeros(t["context"], t["width"]))
+        self.text_projection = nn.Parameter(torch.zeros(t["width"], a["embed_dim"]))
+        self.logit_scale = nn.Parameter(torch.ones([]) * 2.6593)
+        self.token_embedding = nn.Embedding(t["vocab"], t["width"])
+        self.ln_final = nn.LayerNorm(t["width"])
+        self.register_buffer("attn_mask", torch.full((t["context"], t["context"]), float("-inf")).triu_(1),
+                             persistent=False)

@@ -34,6 +34,8 @@ def default_writer(path: str, frames: torch.Tensor, fps: int) -> str:
     """frames: (t, h, w, 3) uint8 CPU.  Returns the path actually written."""
     try:
         import torchvision                                    # noqa: F401
+        if getattr(torchvision, "__tooncrafter_shim__", False):
+            raise ImportError("dropin's torchvision shim has no video encoder")
     except Exception:
         alt = os.path.splitext(path)[0] + ".npy"
         np.save(alt, frames.numpy())
