@@ -114,6 +114,13 @@ def make_inputs(device, seed):
 STAGE_EVENTS = []      # [(name, start, end)] HIP events of the timed steps: where a clip's time goes
 
 
+def _log(msg):
+    if os.environ.get("TC_BENCH_VERBOSE"):
+        torch.cuda.synchronize()
+        sys.stderr.write(f"[bench] {msg}\n")
+        sys.stderr.flush()
+
+
 def _mark():
     e = torch.cuda.Event(enable_timing=True)
     e.record()
@@ -257,6 +264,41 @@ def measure_roofline(model, inp):
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "launches": n, "avg_launch_us": round(ms * 1e3 / max(n, 1), 2),
             "algorithmic_tflop_per_unet_fwd_b2": round(fl / 1e12, 3), "gemm_ms_per_unet_fwd_b2": round(ms, 3)}
+
+
+def measure_boundary(model, inp):
+    """The boundary question (ctypes + hipGraph vs a per-op extension): wall time of ONE B=2 UNet forward and of
+    ONE 16-frame decode, launched eagerly through ctypes (~1130 / ~1000 launches, host-paced) and as a hipGraph
+    replay (one host call).  The product path always replays; the eager figures price what a lower-overhead
+    per-op binding (TORCH_LIBRARY) could at most recover if the graphs did not exist."""
+    un, dec = model.model.diffusion_model, model.first_stage_model.decoder
+    x2, cc2 = torch.cat([inp["x_T"]] * 2), torch.cat([inp["c_concat"]] * 2)
+    ctx2, fs2 = torch.cat([inp["cond"], inp["uncond"]]), torch.cat([inp["fs"]] * 2)
+    ts = torch.full((2,), 499, device=x2.device, dtype=torch.long)
+    z = torch.randn(1, 4, 16, 40, 64, device=x2.device)
+
+    def wall(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+    out = {}
+    with torch.no_grad():
+        un_fwd = lambda: un(None, ts, context=ctx2, fs=fs2, x_parts=[x2, cc2])
+        out["unet_fwd_b2_eager_ms"] = round(wall(un_fwd), 2)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            un_fwd()
+        out["unet_fwd_b2_graph_ms"] = round(wall(g.replay), 2)
+        was = dec.use_hipgraph
+        dec.use_hipgraph = False
+        out["decode_16f_eager_ms"] = round(wall(lambda: dec.decode_clip(z, inp["refs"], scale=1.0 / 0.18215), reps=2), 2)
+        dec.use_hipgraph = was
+        out["decode_16f_graph_ms"] = round(wall(lambda: dec.decode_clip(z, inp["refs"], scale=1.0 / 0.18215), reps=2), 2)
+    return out
 
 
 def cpu_baseline(model, inp):
@@ -409,14 +451,17 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    _log("model built")
     for _ in range(args.warmup):
         step()
+        _log("warmup step done")
     fence()
     STAGE_EVENTS.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         video = step()
     fence()
+    _log("timed steps done")
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], device=device, dtype=torch.float64)
     if world > 1:
@@ -461,10 +506,15 @@ def main():
             torch.cuda.synchronize()
         enc_ms = (time.perf_counter() - te) * 1e3
         result["encoder_16f_ms"] = round(enc_ms, 2)
+        _log("encoder done")
         result["frames_per_s_with_encoder"] = round(16.0 / (dt / args.steps / clips_per_step + enc_ms * 1e-3), 4)
     if rank == 0 and not args.no_roofline:
         result["roofline"] = measure_roofline(model, inps[0])
+        _log("roofline done")
         result["roofline_hbm"] = measure_roofline_hbm(model, inps[0])
+        _log("roofline_hbm done")
+        result["boundary_host_overhead"] = measure_boundary(model, inps[0])
+        _log("boundary done")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(model, inps[0])
     if world > 1:

@@ -25,6 +25,27 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(scope="session", autouse=True)
+def gpu_preflight(request):
+    """Before the first GPU test: a plain-PyTorch health check of the box in a SUBPROCESS (scripts/gpu_health.py:
+    copies, elementwise, GEMM, 64 GiB fill, hipGraph replay -- libtooncrafter_hip.so is not loaded there).
+    One GPU of the pool faults on any sustained work (round-1 driver run, several round-2 leases: always
+    'Memory access fault by GPU node-2', see profiles/r02_node2_*): when the box itself is unhealthy say so and
+    stop, instead of letting the fault be attributed to whichever kernel happened to run."""
+    if not torch.cuda.is_available() or not any("gpu" in item.keywords for item in request.session.items):
+        return
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gpu_health.py")], capture_output=True,
+                           text=True, timeout=600)
+        ok, tail = r.returncode == 0, (r.stdout + r.stderr)[-800:]
+    except subprocess.TimeoutExpired:
+        ok, tail = False, "gpu_health.py timed out after 600 s"
+    if not ok:
+        pytest.exit("GPU BOX UNHEALTHY: scripts/gpu_health.py (plain PyTorch, no tooncrafter code loaded) failed on this "
+                    "lease -- the failure below is the box's, not the kernels':\n" + tail, returncode=3)
+
+
 @pytest.fixture(scope="session")
 def manifest():
     with open(os.path.join(GOLDEN, "manifest.json")) as f:

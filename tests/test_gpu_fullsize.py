@@ -8,11 +8,15 @@ and replayed here; TC_LIVE_ORACLE=1 additionally re-runs the oracle on this host
 
 Stated tolerances (bf16 weights/activations, fp32 accumulation, statistics, softmax and DDIM state), calibrated
 in profiles/r02_noise_floor.txt against the noise floor of the SAME oracle code run under torch bf16 autocast
-on the GPU (bound <= 1.5 x floor):
-  one UNet forward:            rel-L2 <= 2.0e-2 and cosine >= 0.9995
-  decoder, every stage + out:  rel-L2 <= 2.0e-2
-  3-step CFG-7.5 DDIM:         pred_x0 / final latent rel-L2 <= 6e-2 (CFG amplifies the difference of two
-                               forwards by 7.5; the autocast floor of the same run is quoted in the profile)
+on the GPU -- how the reference itself runs (fp16 autocast, inference.py:323) -- per SURVEY.md 8d
+(bound <= 1.5 x floor):
+                               floor (autocast oracle)   HIP path measured   bound here
+  one UNet forward             1.72e-2                   1.44e-2             2.0e-2 (1.16 x floor), cosine >= 0.9995
+  decoder output               1.35e-2                   1.30e-2             2.0e-2 (1.48 x floor)
+  decoder stages               4.8e-3 ... 1.46e-2        4.7e-3 ... 1.44e-2  1.5 x the stage's floor
+  DDIM-3 CFG 7.5 pred_x0       7.1e-2 / 6.3e-2 / 4.5e-2  6.1 / 5.4 / 3.9e-2  1.25 x the step's floor
+  DDIM-3 final latent          4.5e-2                    3.9e-2              5.7e-2 (1.25 x floor)
+(CFG 7.5 multiplies the DIFFERENCE of two forwards, so the trajectory floor is ~4x the single-forward one.)
 """
 import os
 
@@ -29,7 +33,8 @@ DEV = "cuda"
 
 UNET_REL, UNET_COS = 2.0e-2, 0.9995
 DEC_REL = 2.0e-2
-DDIM_REL = 6.0e-2
+DEC_STAGE_FLOOR = {"mid": 4.78e-3, "level3": 4.91e-3, "level2": 7.98e-3, "level1": 1.086e-2, "level0": 1.463e-2}
+DDIM_X0_FLOOR, DDIM_FINAL_FLOOR = (7.144e-2, 6.283e-2, 4.530e-2), 4.523e-2
 
 
 @pytest.fixture(scope="module")
@@ -122,7 +127,7 @@ def test_ddim3_full_size_vs_oracle(full_model, golden, inp):
     print("full-size DDIM-3 CFG 7.5 vs fp32 CPU oracle: pred_x0 rel-L2 per step", [f"{e:.3e}" for e in errs],
           f"final latent {final:.3e}")
     assert torch.isfinite(out).all()
-    assert max(errs) <= DDIM_REL and final <= DDIM_REL
+    assert all(e <= 1.25 * f for e, f in zip(errs, DDIM_X0_FLOOR)) and final <= 1.25 * DDIM_FINAL_FLOOR
 
 
 @pytest.mark.timeout(1500)
@@ -152,4 +157,5 @@ def test_decoder_full_size_vs_oracle(full_model, golden, inp, tag):
     print(f"full-size decoder {tag} vs fp32 CPU oracle: out rel-L2 {e_out:.3e} (|y|/|ref| {norm_ratio:.4f}); stages",
           {n: f"{e:.3e}" for n, e in e_st.items()})
     assert torch.isfinite(y).all() and tuple(y.shape) == (1, 3, z.shape[2], 320, 512)
-    assert e_out <= DEC_REL and max(e_st.values()) <= DEC_REL and abs(norm_ratio - 1.0) < 5e-3
+    assert e_out <= DEC_REL and abs(norm_ratio - 1.0) < 5e-3
+    assert all(e_st[n] <= 1.5 * DEC_STAGE_FLOOR[n] for n in fc.PROBES), e_st

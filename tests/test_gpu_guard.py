@@ -262,3 +262,20 @@ def test_guard_ddim_step(hip, emu, three):
     rp, r0 = emu.ddim_step(x, ec, eu, nz, cfg_scale=7.5, guidance_rescale=0.7, **sc, **kw)
     close(xp, rp, "guard ddim x_prev", rel=1e-4)
     close(x0, r0, "guard ddim x0", rel=1e-4)
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 160, 64), (5, 320, 72), (161, 160, 64)])
+def test_guard_gemm_tile16(hip, emu, monkeypatch, m, n, k):
+    """The 160x160-tile kernel (gemm16.hip) forced onto tiny / ragged problems whose operands end on unmapped memory."""
+    monkeypatch.setenv("TC_GEMM_TILE16", "2")
+    a, w = rnd(m, k, seed=50), rnd(n, k, seed=51, scale=k ** -0.5)
+    bias, res = rnd(n, seed=52, dtype=torch.float32), rnd(m, n, seed=53)
+    out = gout((m, n))
+    hip.gemm(a, w, bias, residual=res, out=out)
+    close(out, emu.gemm(a, w, bias, residual=res), f"guard tile16 gemm {m}x{n}x{k}")
+    x = rnd(3 * 1 * 1, 64, seed=54)
+    wt = rnd(160, 9 * 64, seed=55, scale=(9 * 64) ** -0.5)
+    geom = dict(kind="3x3", frames=3, cin=64, h_in=1, w_in=1, h_out=1, w_out=1, stride=1, upsample=False)
+    out2 = gout((3, 160))
+    hip.gemm(x, wt, None, conv=geom, out=out2)
+    close(out2, emu.gemm(x, wt, None, conv=geom), "guard tile16 conv 1x1 image")

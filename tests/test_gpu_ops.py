@@ -407,3 +407,55 @@ def test_gemm_wide_conv(hip, emu, frames, h, w, cin, cout, t3):
         dict(kind="3x3", frames=frames, cin=cin, h_in=h, w_in=w, h_out=h, w_out=w, stride=1, upsample=False)
     check(hip.gemm(x, wt, bias, conv=geom, residual=res), emu.gemm(x, wt, bias, conv=geom, residual=res),
           f"wide conv t3={t3} f{frames} {h}x{w} {cin}->{cout}")
+
+
+# --------------------------------------------------------------------------- 160x160-tile GEMM (gemm16.hip)
+@pytest.mark.parametrize("m,n,k,kw", [
+    (20480, 640, 640, dict(res=True)),                 # level-1 projection: 512 tiles = one round (heuristic picks it)
+    (81920, 320, 320, dict(res=True, rb=True)),        # level-0 projection: 1024 tiles
+    (1, 160, 64, dict()),                              # one row
+    (77, 320, 328, dict(res=True, act=ACT_SILU)),      # ragged M and K tails
+    (1000, 480, 96, dict(f32=True)),                   # fp32 output, three column tiles
+    (4153, 640, 1280, dict(rb=True, act=ACT_GELU)),    # ragged M over many tiles
+    (163, 160, 2048, dict(res=True)),                  # M just past one tile
+])
+def test_gemm_tile16_linear(hip, emu, monkeypatch, m, n, k, kw):
+    monkeypatch.setenv("TC_GEMM_TILE16", "2")
+    a, w = rnd(m, k, seed=90), rnd(n, k, seed=91, scale=k ** -0.5)
+    bias = rnd(n, seed=92, dtype=torch.float32)
+    res = rnd(m, n, seed=93) if kw.get("res") else None
+    rb = rnd((m + 511) // 512, n, seed=94, dtype=torch.float32) if kw.get("rb") else None
+    args = dict(act=kw.get("act", ACT_NONE), residual=res, row_bias=rb, row_div=512 if rb is not None else 0,
+                out_f32=kw.get("f32", False), alpha=0.9, out_scale=1.1)
+    got = hip.gemm(a, w, bias, **args)
+    monkeypatch.setenv("TC_GEMM_TILE16", "0")
+    other = hip.gemm(a, w, bias, **args)                  # the 128x128 / 256-row kernels on the same problem
+    check(got, emu.gemm(a, w, bias, **args), f"tile16 gemm {m}x{n}x{k} {kw}", f32=kw.get("f32", False))
+    check(got, other, f"tile16 vs 128-tile kernels {m}x{n}x{k}", f32=kw.get("f32", False))
+
+
+def test_gemm_tile16_transpose_detecting(hip, monkeypatch):
+    monkeypatch.setenv("TC_GEMM_TILE16", "2")
+    n = 320
+    a = torch.eye(n, device=DEV, dtype=BF16)
+    w = (torch.arange(n, device=DEV)[:, None] * 3 + torch.arange(n, device=DEV)[None, :] % 7).float()
+    w = (w / w.max()).to(BF16)
+    assert torch.equal(hip.gemm(a, w), w.t().contiguous()), "tile16 C-write layout (row/col) is wrong"
+
+
+@pytest.mark.parametrize("frames,h,w,cin,cout,stride,ups,t3", [
+    (32, 40, 64, 320, 320, 1, False, False), (3, 5, 8, 128, 320, 1, False, False), (2, 10, 16, 64, 160, 2, False, False),
+    (2, 5, 8, 128, 160, 1, True, False), (32, 20, 32, 640, 640, 1, False, True), (6, 3, 5, 64, 160, 1, False, True)])
+def test_gemm_tile16_conv(hip, emu, monkeypatch, frames, h, w, cin, cout, stride, ups, t3):
+    monkeypatch.setenv("TC_GEMM_TILE16", "2")
+    x = rnd(frames * h * w, cin, seed=95)
+    taps = 3 if t3 else 9
+    wt = rnd(cout, taps * cin, seed=96, scale=(taps * cin) ** -0.5)
+    bias = rnd(cout, seed=97, dtype=torch.float32)
+    ho = h * 2 if ups else (h - 1) // stride + 1
+    wo = w * 2 if ups else (w - 1) // stride + 1
+    geom = dict(kind="t3", frames=frames, t_len=frames if frames < 16 else 16, cin=cin, h_out=h, w_out=w) if t3 else \
+        dict(kind="3x3", frames=frames, cin=cin, h_in=h, w_in=w, h_out=ho, w_out=wo, stride=stride, upsample=ups)
+    res = rnd(frames * ho * wo, cout, seed=98) if not t3 else rnd(frames * h * w, cout, seed=98)
+    check(hip.gemm(x, wt, bias, conv=geom, residual=res), emu.gemm(x, wt, bias, conv=geom, residual=res),
+          f"tile16 conv t3={t3} f{frames} {h}x{w} {cin}->{cout} s{stride} ups{ups}")

@@ -454,6 +454,10 @@ extern "C" int tc_gemm_bf16(const TcGemmParams* pp, void* stream) {
     const int v = atoi(e);
     return (v == 22 || v == 21 || v == 12 || v == 11) ? v : 0;
   }();
+  if (force == 0 && tc_gemm_tile16_try(p, batch, s)) {                 // widths 320 k at levels 0 / 1: 160x160 tiles
+    TC_LAUNCH_CHECK();
+    return TC_OK;
+  }
   if (force <= 1 && tc_gemm_wide_try(p, batch, s, force == 1)) {       // big-M layers: 256-row tiles
     TC_LAUNCH_CHECK();
     return TC_OK;

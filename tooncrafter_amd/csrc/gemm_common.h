@@ -200,3 +200,4 @@ inline bool tc_gemm_offsets_fit(const TcGemmParams& p) {
 }
 
 int tc_gemm_wide_try(const TcGemmParams& p, int batch, hipStream_t s, bool force);   // gemm_wide.hip; 1 = launched
+int tc_gemm_tile16_try(const TcGemmParams& p, int batch, hipStream_t s);             // gemm16.hip; 1 = launched

@@ -316,10 +316,9 @@ class VideoDecoder(PackedModule):
         way in (decode_core's 1/scale_factor).  `probe(name, act)` (parity tests only) sees the
         activation after the mid block and after each level's reference fusion.
 
-        The ~1000 launches of one decode are captured in a hipGraph per (latent shape, scale) the second
-        time that geometry is decoded and replayed afterwards (static input/output buffers; the reference
-        rows and K/V are refreshed in place per clip) -- at ~17 us of ctypes host time per eager launch the
-        host, not the GPU, would otherwise pace the decoder."""
+        The ~1000 launches of one decode are captured in a hipGraph per (latent shape, scale) right after the
+        first (eager) decode of that geometry and replayed afterwards (static input/output buffers; the
+        reference rows and K/V are refreshed in place per clip): one host call per decode instead of ~1000."""
         ref = self.ref_cache(ref_context) if ref_context else None
         if not (self.use_hipgraph and z.is_cuda and probe is None and ops.backend().name == "hip"):
             return self._decode(z, ref, scale, probe)
@@ -331,12 +330,14 @@ class VideoDecoder(PackedModule):
         st["z"].copy_(z)
         st["calls"] += 1
         if st["graph"] is None:
-            if st["calls"] < 2:                        # first decode of this geometry runs eagerly (packs, K/V)
-                return self._decode(st["z"], ref, scale, None)
+            # first decode of this geometry: run eagerly (weight packing, reference K/V projection), then record the
+            # graph at once -- capture executes nothing, so the eager result is what this call returns
+            y = self._decode(st["z"], ref, scale, None)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 st["out"] = self._decode(st["z"], ref, scale, None)
             st["graph"] = g
+            return y
         st["graph"].replay()
         return st["out"].clone()
 
