@@ -10,7 +10,7 @@ B="SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAI
 cd /tmp
 for P in a b; do
   CTRS=$A; [ $P = b ] && CTRS=$B
-  rm -rf /tmp/pmc_$TAG_$P
+  rm -rf /tmp/pmc_${TAG}_$P
   timeout -k 5 300 rocprofv3 --kernel-trace --pmc $CTRS -d /tmp/pmc_${TAG}_$P -o pmc -- python $ROOT/$SCRIPT > $OUT/pmc_${TAG}_$P.log 2>&1
   python $ROOT/scripts/pmc_dump.py "$(find /tmp/pmc_${TAG}_$P -name '*.db' | head -1)" "$FLT" > $OUT/pmc_${TAG}_$P.json 2>> $OUT/pmc_${TAG}_$P.log
 done

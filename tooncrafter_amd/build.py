@@ -21,6 +21,10 @@ HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"),
            os.path.join(ROOT, "include", "tooncrafter_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+# per-source flags.  attention.hip: MFMA results straight into VGPRs (gfx950's register file is unified) -- by default
+# hipcc parks the score / output accumulators in AGPRs and the in-register softmax then pays 224 v_accvgpr_read/write
+# moves per 64-key tile
+EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc() -> str:
@@ -36,6 +40,7 @@ def _digest() -> str:
         with open(p, "rb") as f:
             h.update(f.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -61,7 +66,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for s in SOURCES:
         o = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(o)
-        cmd = [hipcc, *FLAGS, f'-DTC_SRC_DIGEST="{dig}"', "-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(s, []), f'-DTC_SRC_DIGEST="{dig}"', "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -17,6 +17,12 @@
 
 namespace {
 
+// v_exp_f32 directly: exp2f() expands to six instructions per value (denormal-range test, two selects, add, exp,
+// ldexp) -- with 32 scores per lane per tile that alone was 200 of the ~900 VALU instructions per tile of a kernel
+// the counters show VALU-bound (29 VALU per MFMA, profiles/r02_pmc_attention.json).  Arguments here are <= 0 and
+// results below 2^-126 may flush to zero: exactly what a masked or negligible probability should be.
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 constexpr int KT = 64;            // keys per tile
 constexpr int K_STRIDE = 144;     // bytes per K row in LDS (128 + 16 pad): conflict-free ds_read_b128
 constexpr int VT_STRIDE = 136;    // bytes per V^T row (64 keys * 2 + 8 pad): conflict-free ds_read_b64
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(256) void attn_d64_kernel(const TcAttnParams p) {
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx * c);         // c > 0: max commutes with the scale
     if (!__all(m_new == m_run)) {
-      const float alpha = exp2f(m_run - m_new);
+      const float alpha = fast_exp2(m_run - m_new);
       l_run *= alpha;
 #pragma unroll
       for (int d = 0; d < 2; ++d)
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(256) void attn_d64_kernel(const TcAttnParams p) {
     for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = exp2f(fmaf(st[kbk][r], c, -m_run));   // masked keys: exp2(-huge) = 0
+        const float pv = fast_exp2(fmaf(st[kbk][r], c, -m_run));   // masked keys: exp2(-huge) = 0
         st[kbk][r] = pv;
         rs += pv;
       }
@@ -308,14 +314,14 @@ __global__ __launch_bounds__(256) void attn_d64_dma_kernel(const TcAttnParams p)
     const char* vs = ks + KD_TILE;
 
     f32x16 st[2];
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kbk = 0; kbk < 2; ++kbk) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st[kbk][r] = 0.f;
-#pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + kbk * 32 * 128 + k_off[kk]);
-        st[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st[kbk], 0, 0, 0);
+        // the first product takes the inline constant 0 as its C operand: no 32 v_mov per tile to clear st
+        st[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], kk == 0 ? zero16 : st[kbk], 0, 0, 0);
       }
     }
     if (key0 + KT > p.lk) {
@@ -335,7 +341,7 @@ __global__ __launch_bounds__(256) void attn_d64_dma_kernel(const TcAttnParams p)
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx * c);
     if (!__all(m_new == m_run)) {
-      const float alpha = exp2f(m_run - m_new);
+      const float alpha = fast_exp2(m_run - m_new);
       l_run *= alpha;
 #pragma unroll
       for (int d = 0; d < 2; ++d)
@@ -348,7 +354,7 @@ __global__ __launch_bounds__(256) void attn_d64_dma_kernel(const TcAttnParams p)
     for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = exp2f(fmaf(st[kbk][r], c, -m_run));
+        const float pv = fast_exp2(fmaf(st[kbk][r], c, -m_run));
         st[kbk][r] = pv;
         rs += pv;
       }
