@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TC_ABI_VERSION 5
+#define TC_ABI_VERSION 6
 
 enum {
   TC_OK = 0,
@@ -106,6 +106,13 @@ typedef struct TcAttnParams {
   int32_t kv_bdiv;     /* K/V batch index = b / kv_bdiv (shared reference / text keys) */
   int32_t accumulate;  /* 1: o += result (second softmax of the image cross-attention) */
   float scale;         /* d^-0.5 */
+  /* ABI 6 -- optional SECOND key/value set with its own softmax, summed into the same output in one launch:
+   * o = softmax(q k^T) v + softmax(q k2^T) v2 -- the text + image cross-attention of attention.py:153-207
+   * (77 text keys shared by the frames of a clip, 16 image keys per frame).  k2 == NULL: single set. */
+  const tc_bf16* k2; const tc_bf16* v2;
+  int32_t lk2, kv2_bdiv;
+  int64_t k2_sb, v2_sb;
+  int32_t k2_ss, v2_ss;
 } TcAttnParams;
 
 /* softmax(q k^T * scale) v, head dim 64, flash-style (scores never leave the CU).

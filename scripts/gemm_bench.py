@@ -110,3 +110,10 @@ if __name__ == "__main__":
     attn(32, 5, 2560, 77, 16, tag="L0 text")
     attn(32, 5, 2560, 16, 1, tag="L0 image")
     attn(16, 8, 10240, 20480, 16, tag="dec L2 ref")
+    # text + image cross-attention as ONE launch (two softmaxes)
+    c = 5 * 64
+    q = torch.randn(32 * 2560, c, device=dev).to(BF)
+    kvt, kvi = torch.randn(2 * 77, 2 * c, device=dev).to(BF), torch.randn(32 * 16, 2 * c, device=dev).to(BF)
+    ms = timeit(lambda: hip.attention(q, kvt[:, :c], kvt[:, c:], batch=32, heads=5, lq=2560, lk=77, kv_bdiv=16,
+                                      k2=kvi[:, :c], v2=kvi[:, c:], lk2=16, kv2_bdiv=1))
+    print(f"attn    L0 text+image fused  b=32 h=5 lq=2560 lk=77+16  {ms*1e3:8.1f} us")

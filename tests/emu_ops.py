@@ -100,18 +100,24 @@ class EmuOps:
         return res.contiguous()
 
     # ------------------------------------------------------------------ attention
-    def attention(self, q, k, v, *, batch, heads, lq, lk, kv_bdiv=1, out=None, accumulate=False, scale=None):
+    def attention(self, q, k, v, *, batch, heads, lq, lk, kv_bdiv=1, out=None, accumulate=False, scale=None,
+                  k2=None, v2=None, lk2=0, kv2_bdiv=1):
         scale = 64 ** -0.5 if scale is None else scale
         qf = _f(q).reshape(batch, lq, heads, 64).permute(0, 2, 1, 3)
-        kvb = (batch + kv_bdiv - 1) // kv_bdiv
-        kf = _f(k).reshape(kvb, lk, heads, 64).permute(0, 2, 1, 3)
-        vf = _f(v).reshape(kvb, lk, heads, 64).permute(0, 2, 1, 3)
-        idx = (torch.arange(batch) // kv_bdiv).tolist()
-        outs = []
-        for i in range(batch):
-            s = (qf[i] @ kf[idx[i]].transpose(-1, -2)) * scale
-            outs.append(s.softmax(-1) @ vf[idx[i]])
-        o = torch.stack(outs).permute(0, 2, 1, 3).reshape(batch * lq, heads * 64)
+
+        def one(k, v, lk, kv_bdiv):
+            kvb = (batch + kv_bdiv - 1) // kv_bdiv
+            kf = _f(k).reshape(kvb, lk, heads, 64).permute(0, 2, 1, 3)
+            vf = _f(v).reshape(kvb, lk, heads, 64).permute(0, 2, 1, 3)
+            idx = (torch.arange(batch) // kv_bdiv).tolist()
+            outs = []
+            for i in range(batch):
+                s = (qf[i] @ kf[idx[i]].transpose(-1, -2)) * scale
+                outs.append(s.softmax(-1) @ vf[idx[i]])
+            return torch.stack(outs).permute(0, 2, 1, 3).reshape(batch * lq, heads * 64)
+        o = one(k, v, lk, kv_bdiv)
+        if k2 is not None:                     # second softmax summed in fp32, rounded once (the fused kernel's contract)
+            o = o + one(k2, v2, lk2, kv2_bdiv)
         if accumulate:
             o = o + _f(out)
         o = self._out(o)

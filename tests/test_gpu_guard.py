@@ -279,3 +279,13 @@ def test_guard_gemm_tile16(hip, emu, monkeypatch, m, n, k):
     out2 = gout((3, 160))
     hip.gemm(x, wt, None, conv=geom, out=out2)
     close(out2, emu.gemm(x, wt, None, conv=geom), "guard tile16 conv 1x1 image")
+
+
+def test_guard_attention_dual_kv(hip, emu):
+    batch, heads, lq, lk, lk2 = 4, 1, 5, 77, 16
+    q, k, v = rnd(batch * lq, 64, seed=60), rnd(1 * lk, 64, seed=61), rnd(1 * lk, 64, seed=62)
+    k2, v2 = rnd(batch * lk2, 64, seed=63), rnd(batch * lk2, 64, seed=64)
+    out = gout((batch * lq, 64))
+    kw = dict(batch=batch, heads=heads, lq=lq, lk=lk, kv_bdiv=4, k2=k2, v2=v2, lk2=lk2, kv2_bdiv=1)
+    hip.attention(q, k, v, out=out, **kw)
+    close(out, emu.attention(q, k, v, **kw), "guard dual attention")

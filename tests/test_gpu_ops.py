@@ -459,3 +459,23 @@ def test_gemm_tile16_conv(hip, emu, monkeypatch, frames, h, w, cin, cout, stride
     res = rnd(frames * ho * wo, cout, seed=98) if not t3 else rnd(frames * h * w, cout, seed=98)
     check(hip.gemm(x, wt, bias, conv=geom, residual=res), emu.gemm(x, wt, bias, conv=geom, residual=res),
           f"tile16 conv t3={t3} f{frames} {h}x{w} {cin}->{cout} s{stride} ups{ups}")
+
+
+# --------------------------------------------------------------------------- two key/value sets, two softmaxes, one launch
+@pytest.mark.parametrize("batch,heads,lq,lk,div,lk2,div2", [
+    (32, 5, 2560, 77, 16, 16, 1),      # level-0 cross-attention: 77 text keys per clip, 16 image keys per frame
+    (8, 2, 100, 77, 4, 16, 1), (4, 1, 33, 77, 4, 64, 4), (2, 3, 130, 200, 1, 65, 2), (3, 1, 1, 1, 1, 1, 1)])
+def test_attention_dual_kv(hip, emu, batch, heads, lq, lk, div, lk2, div2):
+    c = heads * 64
+    q = rnd(batch * lq, c, seed=110)
+    kv = rnd(((batch + div - 1) // div) * lk, 2 * c, seed=111)
+    kv2 = rnd(((batch + div2 - 1) // div2) * lk2, 2 * c, seed=112)
+    kw = dict(batch=batch, heads=heads, lq=lq, lk=lk, kv_bdiv=div)
+    kw2 = dict(k2=kv2[:, :c], v2=kv2[:, c:], lk2=lk2, kv2_bdiv=div2)
+    got = hip.attention(q, kv[:, :c], kv[:, c:], **kw, **kw2)
+    check(got, emu.attention(q, kv[:, :c], kv[:, c:], **kw, **kw2), f"dual attention b{batch} h{heads} lq{lq} lk{lk}+{lk2}",
+          rel=8e-3)
+    # against the two-launch form it replaces (second launch accumulates into the bf16 result of the first)
+    two = hip.attention(q, kv[:, :c], kv[:, c:], **kw)
+    hip.attention(q, kv2[:, :c], kv2[:, c:], batch=batch, heads=heads, lq=lq, lk=lk2, kv_bdiv=div2, out=two, accumulate=True)
+    check(got, two, "dual attention vs two launches", rel=8e-3)

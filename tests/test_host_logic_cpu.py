@@ -305,7 +305,12 @@ def test_openclip_conditioners_resolve_and_carry_open_clip_names():
             "model.visual.transformer.resblocks.0.mlp.c_proj.weight", "model.visual.ln_post.weight",
             "model.visual.proj"} <= kv
     assert sum(p.numel() for p in t.parameters()) == 354_032_641          # ViT-H/14 text tower
-    assert sum(p.numel() for p in v.parameters()) == 632_076_800          # ViT-H/14 vision tower
+    assert sum(p.numel() for p in v.model.visual.parameters()) == 632_076_800   # ViT-H/14 vision tower
+    # the reference deletes only `model.transformer`: the rest of CLIP's text half stays in the module, hence in every
+    # checkpoint -- dead weights that load_state_dict(strict=True) (inference.py:32,44) must find a home for
+    assert {"model.positional_embedding", "model.text_projection", "model.logit_scale", "model.token_embedding.weight",
+            "model.ln_final.weight", "model.ln_final.bias"} <= set(v.state_dict())
+    assert "model.attn_mask" not in v.state_dict() and not any(k.startswith("model.transformer.") for k in v.state_dict())
     assert tuple(v.state_dict()["model.visual.positional_embedding"].shape) == (257, 1280)
     import pytest
     with pytest.raises(RuntimeError):

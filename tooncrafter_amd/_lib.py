@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libtooncrafter_hip.so")
 
-TC_ABI_VERSION = 5
+TC_ABI_VERSION = 6
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_GEGLU = 0, 1, 2, 3
 GATHER_LINEAR, GATHER_CONV3x3, GATHER_CONVT3 = 0, 1, 2
 
@@ -44,6 +44,8 @@ class TcAttnParams(C.Structure):
         ("q_sb", C.c_int64), ("k_sb", C.c_int64), ("v_sb", C.c_int64), ("o_sb", C.c_int64),
         ("q_ss", C.c_int32), ("k_ss", C.c_int32), ("v_ss", C.c_int32), ("o_ss", C.c_int32),
         ("kv_bdiv", C.c_int32), ("accumulate", C.c_int32), ("scale", C.c_float),
+        ("k2", C.c_void_p), ("v2", C.c_void_p), ("lk2", C.c_int32), ("kv2_bdiv", C.c_int32),
+        ("k2_sb", C.c_int64), ("v2_sb", C.c_int64), ("k2_ss", C.c_int32), ("v2_ss", C.c_int32),
     ]
 
 

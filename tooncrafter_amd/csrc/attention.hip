@@ -227,6 +227,7 @@ __device__ __forceinline__ u32x2 lds_read_tr16_b64(const char* p) {
   return __builtin_bit_cast(u32x2, v);
 }
 
+template <bool DUAL>
 __global__ __launch_bounds__(256) void attn_d64_dma_kernel(const TcAttnParams p) {
   __shared__ __attribute__((aligned(1024))) char smem[2 * DMA_STAGE];
 
@@ -234,14 +235,8 @@ __global__ __launch_bounds__(256) void attn_d64_dma_kernel(const TcAttnParams p)
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int l31 = lane & 31, half = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int kvb = b / p.kv_bdiv;
   const bf16_t* qb = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.q_sb + h * 64;
-  const bf16_t* kb = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)kvb * p.k_sb + h * 64;
-  const bf16_t* vb = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)kvb * p.v_sb + h * 64;
   bf16_t* ob = reinterpret_cast<bf16_t*>(p.o) + (int64_t)b * p.o_sb + h * 64;
-  // descriptors over exactly the lk rows of this (batch, head): a key row >= lk is out of range and reads as zeros
-  const tc_rsrc_t k_rsrc = make_rsrc(kb, ((int64_t)(p.lk - 1) * p.k_ss + 64) * 2);
-  const tc_rsrc_t v_rsrc = make_rsrc(vb, ((int64_t)(p.lk - 1) * p.v_ss + 64) * 2);
 
   const int q_row = blockIdx.x * 128 + wave * 32 + l31;
   const int q_ld = q_row < p.lq ? q_row : p.lq - 1;   // clamp: tail rows compute garbage, never stored
@@ -249,32 +244,6 @@ __global__ __launch_bounds__(256) void attn_d64_dma_kernel(const TcAttnParams p)
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk)
     qf[kk] = *reinterpret_cast<const bf16x8*>(qb + (int64_t)q_ld * p.q_ss + kk * 16 + half * 8);
-
-  // ---- DMA geometry: a tile is 8 pieces of 8 key rows per matrix; wave w issues pieces w and w + 4.  Lane l of a
-  // piece lands at (row l>>3, physical chunk l&7) and therefore FETCHES the logical chunk whose swizzled home that is.
-  const int prow = lane >> 3;
-  uint32_t k_voff[2], v_voff[2];
-  int piece_row[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = (wave + 4 * i) * 8 + prow;                  // key row inside the tile
-    piece_row[i] = row;
-    const int kchunk = (lane & 7) ^ ((row >> 1) & 7);
-    const int vchunk = (lane & 7) ^ (((row >> 1) & 1) << 2);
-    k_voff[i] = (uint32_t)(row * p.k_ss * 2 + kchunk * 16);
-    v_voff[i] = (uint32_t)(row * p.v_ss * 2 + vchunk * 16);
-  }
-  auto dma_tile = [&](int kt, int stage) {
-    const int key0 = kt * KT;
-    char* sk = smem + stage * DMA_STAGE + wave_u * 1024;
-    char* sv = sk + KD_TILE;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const uint32_t dead = (key0 + piece_row[i] < p.lk) ? 0u : TC_OOB;      // ragged last tile: zero rows
-      glds16(k_rsrc, sk + i * 4096, k_voff[i] | dead, (uint32_t)key0 * (uint32_t)p.k_ss * 2u);
-      glds16(v_rsrc, sv + i * 4096, v_voff[i] | dead, (uint32_t)key0 * (uint32_t)p.v_ss * 2u);
-    }
-  };
 
   // ---- fragment read offsets (per lane, fixed for the whole kernel)
   // K (A operand of S^T = K Q^T): lane (key l31 of block kbk, k = 16 kk + 8 half ..): 16-byte chunk 2 kk + half of its row
@@ -300,85 +269,139 @@ __global__ __launch_bounds__(256) void attn_d64_dma_kernel(const TcAttnParams p)
   for (int d = 0; d < 2; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+  const int prow = lane >> 3;
 
-  const int n_tiles = (p.lk + KT - 1) / KT;
-  dma_tile(0, 0);
-  for (int kt = 0; kt < n_tiles; ++kt) {
-    const int key0 = kt * KT;
-    // tile kt has landed for this wave (vmcnt) and for every wave (barrier); the same barrier retires all reads
-    // of the buffer the next DMA overwrites
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < n_tiles) dma_tile(kt + 1, (kt + 1) & 1);
-    const char* ks = smem + (kt & 1) * DMA_STAGE;
-    const char* vs = ks + KD_TILE;
-
-    f32x16 st[2];
-    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // One key/value stream: online softmax over its lk keys into (m_run, l_run, oacc).
+  auto run_stream = [&](const bf16_t* kb, const bf16_t* vb, const int lk, const int k_ss, const int v_ss) {
+    // descriptors over exactly the lk rows of this (batch, head): a key row >= lk is out of range and reads as zeros
+    const tc_rsrc_t k_rsrc = make_rsrc(kb, ((int64_t)(lk - 1) * k_ss + 64) * 2);
+    const tc_rsrc_t v_rsrc = make_rsrc(vb, ((int64_t)(lk - 1) * v_ss + 64) * 2);
+    // DMA geometry: a tile is 8 pieces of 8 key rows per matrix; wave w issues pieces w and w + 4.  Lane l of a piece
+    // lands at (row l>>3, physical chunk l&7) and therefore FETCHES the logical chunk whose swizzled home that is.
+    uint32_t k_voff[2], v_voff[2];
+    int piece_row[2];
 #pragma unroll
-    for (int kbk = 0; kbk < 2; ++kbk) {
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + kbk * 32 * 128 + k_off[kk]);
-        // the first product takes the inline constant 0 as its C operand: no 32 v_mov per tile to clear st
-        st[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], kk == 0 ? zero16 : st[kbk], 0, 0, 0);
-      }
+    for (int i = 0; i < 2; ++i) {
+      const int row = (wave + 4 * i) * 8 + prow;                  // key row inside the tile
+      piece_row[i] = row;
+      const int kchunk = (lane & 7) ^ ((row >> 1) & 7);
+      const int vchunk = (lane & 7) ^ (((row >> 1) & 1) << 2);
+      k_voff[i] = (uint32_t)(row * k_ss * 2 + kchunk * 16);
+      v_voff[i] = (uint32_t)(row * v_ss * 2 + vchunk * 16);
     }
-    if (key0 + KT > p.lk) {
+    auto dma_tile = [&](int kt, int stage) {
+      const int key0 = kt * KT;
+      char* sk = smem + stage * DMA_STAGE + wave_u * 1024;
+      char* sv = sk + KD_TILE;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const uint32_t dead = (key0 + piece_row[i] < lk) ? 0u : TC_OOB;      // ragged last tile: zero rows
+        glds16(k_rsrc, sk + i * 4096, k_voff[i] | dead, (uint32_t)key0 * (uint32_t)k_ss * 2u);
+        glds16(v_rsrc, sv + i * 4096, v_voff[i] | dead, (uint32_t)key0 * (uint32_t)v_ss * 2u);
+      }
+    };
+
+    const int n_tiles = (lk + KT - 1) / KT;
+    dma_tile(0, 0);
+    for (int kt = 0; kt < n_tiles; ++kt) {
+      const int key0 = kt * KT;
+      // tile kt has landed for this wave (vmcnt) and for every wave (barrier); the same barrier retires all reads
+      // of the buffer the next DMA overwrites
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt + 1 < n_tiles) dma_tile(kt + 1, (kt + 1) & 1);
+      const char* ks = smem + (kt & 1) * DMA_STAGE;
+      const char* vs = ks + KD_TILE;
+
+      f32x16 st[2];
+      const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kbk = 0; kbk < 2; ++kbk) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + kbk * 32 * 128 + k_off[kk]);
+          // the first product takes the inline constant 0 as its C operand: no 32 v_mov per tile to clear st
+          st[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], kk == 0 ? zero16 : st[kbk], 0, 0, 0);
+        }
+      }
+      if (key0 + KT > lk) {
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = key0 + kbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            st[kbk][r] = key < lk ? st[kbk][r] : -1e30f;
+          }
+      }
+      float mx = st[0][0];
+#pragma unroll
+      for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kbk][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx * c);
+      if (!__all(m_new == m_run)) {
+        const float alpha = fast_exp2(m_run - m_new);
+        l_run *= alpha;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+        m_run = m_new;
+      }
+      float rs = 0.f;
 #pragma unroll
       for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int key = key0 + kbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          st[kbk][r] = key < p.lk ? st[kbk][r] : -1e30f;
+          const float pv = fast_exp2(fmaf(st[kbk][r], c, -m_run));
+          st[kbk][r] = pv;
+          rs += pv;
         }
-    }
-    float mx = st[0][0];
-#pragma unroll
-    for (int kbk = 0; kbk < 2; ++kbk)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kbk][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx * c);
-    if (!__all(m_new == m_run)) {
-      const float alpha = fast_exp2(m_run - m_new);
-      l_run *= alpha;
-#pragma unroll
-      for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
-      m_run = m_new;
-    }
-    float rs = 0.f;
-#pragma unroll
-    for (int kbk = 0; kbk < 2; ++kbk)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = fast_exp2(fmaf(st[kbk][r], c, -m_run));
-        st[kbk][r] = pv;
-        rs += pv;
-      }
-    rs += __shfl_xor(rs, 32, 64);
-    l_run += rs;
+      rs += __shfl_xor(rs, 32, 64);
+      l_run += rs;
 
-    // O^T += V^T P^T: k-slot (half, j) of slab s in key block kbk carries key kbk*32 + 16 s + 8 (j>>2) + 4 half + (j&3)
-    // for both operands; the V side is two transposing reads (keys +0..3 and +8..11 of the slab) per fragment
+      // O^T += V^T P^T: k-slot (half, j) of slab s in key block kbk carries key kbk*32 + 16 s + 8 (j>>2) + 4 half + (j&3)
+      // for both operands; the V side is two transposing reads (keys +0..3 and +8..11 of the slab) per fragment
 #pragma unroll
-    for (int kbk = 0; kbk < 2; ++kbk)
+      for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        bf16x8 pf;
+        for (int s = 0; s < 2; ++s) {
+          bf16x8 pf;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)st[kbk][8 * s + j];
-        const int kbase = (kbk * 32 + 16 * s + 4 * half) * 128;
+          for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)st[kbk][8 * s + j];
+          const int kbase = (kbk * 32 + 16 * s + 4 * half) * 128;
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
-          const u32x2 lo = lds_read_tr16_b64(vs + kbase + v_off[d]);
-          const u32x2 hi = lds_read_tr16_b64(vs + kbase + 8 * 128 + v_off[d]);
-          u32x4 vv = {lo[0], lo[1], hi[0], hi[1]};
-          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, oacc[d], 0, 0, 0);
+          for (int d = 0; d < 2; ++d) {
+            const u32x2 lo = lds_read_tr16_b64(vs + kbase + v_off[d]);
+            const u32x2 hi = lds_read_tr16_b64(vs + kbase + 8 * 128 + v_off[d]);
+            u32x4 vv = {lo[0], lo[1], hi[0], hi[1]};
+            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, oacc[d], 0, 0, 0);
+          }
         }
-      }
+    }
+  };
+
+  {
+    const int kvb = b / p.kv_bdiv;
+    run_stream(reinterpret_cast<const bf16_t*>(p.k) + (int64_t)kvb * p.k_sb + h * 64,
+               reinterpret_cast<const bf16_t*>(p.v) + (int64_t)kvb * p.v_sb + h * 64, p.lk, p.k_ss, p.v_ss);
+  }
+  // second key/value set (text + image cross-attention): normalise the first result, keep it in fp32, start a fresh
+  // softmax; the sum is rounded to bf16 once
+  f32x16 o1[2];
+  if (DUAL) {
+    const float inv1 = 1.0f / l_run;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o1[d][r] = oacc[d][r] * inv1; oacc[d][r] = 0.f; }
+    m_run = -1e30f;
+    l_run = 0.f;
+    __syncthreads();                     // every wave has finished reading the first stream's last tile
+    const int kvb2 = b / p.kv2_bdiv;
+    run_stream(reinterpret_cast<const bf16_t*>(p.k2) + (int64_t)kvb2 * p.k2_sb + h * 64,
+               reinterpret_cast<const bf16_t*>(p.v2) + (int64_t)kvb2 * p.v2_sb + h * 64, p.lk2, p.k2_ss, p.v2_ss);
   }
 
   if (q_row < p.lq) {
@@ -391,6 +414,7 @@ __global__ __launch_bounds__(256) void attn_d64_dma_kernel(const TcAttnParams p)
         const int dim = d * 32 + 8 * g + 4 * half;
         float x0 = oacc[d][4 * g + 0] * inv, x1 = oacc[d][4 * g + 1] * inv;
         float x2 = oacc[d][4 * g + 2] * inv, x3 = oacc[d][4 * g + 3] * inv;
+        if (DUAL) { x0 += o1[d][4 * g + 0]; x1 += o1[d][4 * g + 1]; x2 += o1[d][4 * g + 2]; x3 += o1[d][4 * g + 3]; }
         u32x2* dst = reinterpret_cast<u32x2*>(orow + dim);
         if (p.accumulate) {
           const u32x2 old = *dst;
@@ -501,15 +525,27 @@ extern "C" int tc_attn_d64(const TcAttnParams* pp, void* stream) {
   if ((p.q_ss & 7) || (p.k_ss & 7) || (p.v_ss & 7) || (p.o_ss & 7)) return TC_EALIGN;
   if ((p.q_sb & 7) || (p.k_sb & 7) || (p.v_sb & 7) || (p.o_sb & 7)) return TC_EALIGN;
   if (p.heads > 65535 || p.batch > 65535) return TC_ESHAPE;
+  const bool dual = p.k2 != nullptr;
+  if (dual) {
+    if (!p.v2 || p.lk2 <= 0 || p.kv2_bdiv <= 0) return TC_EINVAL;
+    if (!tc_aligned16(p.k2) || !tc_aligned16(p.v2) || (p.k2_ss & 7) || (p.v2_ss & 7) || (p.k2_sb & 7) || (p.v2_sb & 7))
+      return TC_EALIGN;
+  }
   dim3 grid((p.lq + 127) / 128, p.heads, p.batch), block(256);
   // TC_ATTN_STAGE=reg selects the register-staged kernel (A/B runs); the DMA-staged one needs 31-bit row offsets
   static const bool use_reg = [] { const char* e = getenv("TC_ATTN_STAGE"); return e && e[0] == 'r'; }();
   const bool fits = (int64_t)p.lk * p.k_ss * 2 < 0x7fffff00LL && (int64_t)p.lk * p.v_ss * 2 < 0x7fffff00LL &&
                     p.k_ss >= 64 && p.v_ss >= 64;
-  if (!use_reg && fits)
-    hipLaunchKernelGGL(attn_d64_dma_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream), p);
-  else
+  if (dual) {
+    const bool fits2 = (int64_t)p.lk2 * p.k2_ss * 2 < 0x7fffff00LL && (int64_t)p.lk2 * p.v2_ss * 2 < 0x7fffff00LL &&
+                       p.k2_ss >= 64 && p.v2_ss >= 64;
+    if (!fits || !fits2) return TC_ESHAPE;
+    hipLaunchKernelGGL(attn_d64_dma_kernel<true>, grid, block, 0, reinterpret_cast<hipStream_t>(stream), p);
+  } else if (!use_reg && fits) {
+    hipLaunchKernelGGL(attn_d64_dma_kernel<false>, grid, block, 0, reinterpret_cast<hipStream_t>(stream), p);
+  } else {
     hipLaunchKernelGGL(attn_d64_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream), p);
+  }
   TC_LAUNCH_CHECK();
   return TC_OK;
 }

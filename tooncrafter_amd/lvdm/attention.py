@@ -180,14 +180,18 @@ class CrossAttention(PackedModule):
         c = self.heads * 64
         kv_text, kv_img = self.context_kv(ctx)
         q = ops.gemm(x_norm, pk["wq"])
-        a = ops.attention(q, kv_text[:, :c], kv_text[:, c:], batch=act.frames, heads=self.heads, lq=act.hw,
-                          lk=ctx.text_len, kv_bdiv=act.t, scale=self.scale)
         if kv_img is not None:
             if self.image_cross_attention_scale != 1.0:
                 raise NotImplementedError("image_cross_attention_scale != 1.0")
-            ops.attention(q, kv_img[:, :c], kv_img[:, c:], batch=act.frames, heads=self.heads, lq=act.hw,
-                          lk=ctx.img_len, kv_bdiv=1 if ctx.img_per_frame else act.t, out=a, accumulate=True,
-                          scale=self.scale)
+            # text and image softmaxes in ONE launch (attention.py:153-207 runs two attentions and adds them): Q is read
+            # once and the sum is formed in fp32 registers -- no bf16 round trip of the first result through HBM
+            a = ops.attention(q, kv_text[:, :c], kv_text[:, c:], batch=act.frames, heads=self.heads, lq=act.hw,
+                              lk=ctx.text_len, kv_bdiv=act.t, scale=self.scale,
+                              k2=kv_img[:, :c], v2=kv_img[:, c:], lk2=ctx.img_len,
+                              kv2_bdiv=1 if ctx.img_per_frame else act.t)
+        else:
+            a = ops.attention(q, kv_text[:, :c], kv_text[:, c:], batch=act.frames, heads=self.heads, lq=act.hw,
+                              lk=ctx.text_len, kv_bdiv=act.t, scale=self.scale)
         return ops.gemm(a, pk["wo"], pk["bo"], residual=residual)
 
 

@@ -152,9 +152,11 @@ class HipOps:
         return out
 
     # ------------------------------------------------------------------ attention
-    def attention(self, q, k, v, *, batch, heads, lq, lk, kv_bdiv=1, out=None, accumulate=False, scale=None):
+    def attention(self, q, k, v, *, batch, heads, lq, lk, kv_bdiv=1, out=None, accumulate=False, scale=None,
+                  k2=None, v2=None, lk2=0, kv2_bdiv=1):
         """q: [batch*lq, heads*64] rows view; k, v: [(batch//kv_bdiv)*lk, heads*64] rows views.
-        out[batch*lq, heads*64] (+)= softmax(q k^T * scale) v per (batch, head)."""
+        out[batch*lq, heads*64] (+)= softmax(q k^T * scale) v per (batch, head)
+        [+ softmax(q k2^T * scale) v2 when a second key/value set is given: two softmaxes, one launch]."""
         q, k, v = _rows_view(q), _rows_view(k), _rows_view(v)
         hd = heads * 64
         if q.shape != (batch * lq, hd) or k.shape[1] != hd or v.shape[1] != hd:
@@ -176,6 +178,14 @@ class HipOps:
         p.kv_bdiv = kv_bdiv
         p.accumulate = 1 if accumulate else 0
         p.scale = float(scale if scale is not None else 64 ** -0.5)
+        if k2 is not None:
+            k2, v2 = _rows_view(k2), _rows_view(v2)
+            kvb2 = (batch + kv2_bdiv - 1) // kv2_bdiv
+            if lk2 <= 0 or k2.shape != (kvb2 * lk2, hd) or v2.shape != (kvb2 * lk2, hd):
+                raise ValueError("attention: second K/V set must be [(batch//kv2_bdiv)*lk2, heads*64]")
+            p.k2, p.v2, p.lk2, p.kv2_bdiv = k2.data_ptr(), v2.data_ptr(), lk2, kv2_bdiv
+            p.k2_ss, p.v2_ss = k2.stride(0), v2.stride(0)
+            p.k2_sb, p.v2_sb = lk2 * k2.stride(0), lk2 * v2.stride(0)
         _lib.check(self.lib.tc_attn_d64(C.byref(p), _stream()), "tc_attn_d64")
         return out
 
