@@ -479,3 +479,21 @@ def test_attention_dual_kv(hip, emu, batch, heads, lq, lk, div, lk2, div2):
     two = hip.attention(q, kv[:, :c], kv[:, c:], **kw)
     hip.attention(q, kv2[:, :c], kv2[:, c:], batch=batch, heads=heads, lq=lq, lk=lk2, kv_bdiv=div2, out=two, accumulate=True)
     check(got, two, "dual attention vs two launches", rel=8e-3)
+
+
+def test_groupnorm_large_mean_two_pass(hip):
+    """Activations with a large common offset (mean 60, spread 1): the variance must come out of a true two-pass
+    sum((x - mean)^2) or an equally careful accumulation, not of E[x^2] - mean^2 in low precision.  Against float64."""
+    for samples, rows, c in ((4, 160, 1280), (2, 2560, 320), (2, 10240, 640)):   # single-pass (two sizes) and 3-launch path
+        gen = torch.Generator().manual_seed(77)
+        x = (torch.randn(samples * rows, c, generator=gen) + 60.0).to(BF16).to(DEV)
+        g = torch.ones(c, device=DEV)
+        b = torch.zeros(c, device=DEV)
+        got = hip.groupnorm(x, g, b, samples=samples, rows=rows, eps=1e-5, silu=False)
+        xd = x.double().reshape(samples, rows, 32, c // 32).permute(0, 2, 1, 3)
+        mean = xd.mean(dim=(2, 3), keepdim=True)
+        var = ((xd - mean) ** 2).mean(dim=(2, 3), keepdim=True)
+        ref = ((xd - mean) / (var + 1e-5).sqrt()).permute(0, 2, 1, 3).reshape(samples * rows, c)
+        err = float((got.double() - ref).norm() / ref.norm())
+        print(f"groupnorm mean 60 +- 1, s{samples} r{rows} c{c}: rel-L2 vs float64 {err:.3e}")
+        assert err < 6e-3, err          # bf16 output rounding is 2e-3..4e-3 of a unit-variance result

@@ -217,6 +217,132 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __re
 }
 
 // ---------------------------------------------------------------------------------------
+// Single-pass GroupNorm for slabs that fit a block's registers.  A block owns one (sample, unit) where a unit is
+// U = lcm(8, C/32) channels (whole 8-channel vectors AND whole groups: 40 channels = 4 groups at C = 320, 2 at 640,
+// 1 at 1280; 120 at C = 960 / 1920; 80 at 2560).  Every thread is pinned to one 8-channel vector of the unit and walks
+// the rows, keeping its NV vectors (packed bf16) in registers: x is read from memory ONCE (the three-launch path reads
+// it twice), the variance is the true two-pass sum((x - mean)^2) (no E[x^2] - mean^2 cancellation), and the whole norm
+// is one launch instead of three -- for the level-2/3 tensors of the UNet (3-13 MB) the launches, not the bytes, were
+// the cost (~15 us for 1-4 us of traffic).  Reductions: per-lane group contributions -> wave shuffles -> one LDS slot
+// per (wave, group) -> summed in wave order by every thread: no atomics, bit-reproducible.
+// keeps the compiler from carrying the UNPACKED fp32 copies of the slab from one pass to the next (8 registers per
+// vector instead of 4: the 26-vector instance would spill): after this the packed words are "new" values
+__device__ __forceinline__ void gn_opaque(u32x4& v) { asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])); }
+
+template <int T, int NV>
+__global__ __launch_bounds__(T) void gn_onepass_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       int rows, int c, int vu, float eps, int silu) {
+  constexpr int NW = T / 64;
+  __shared__ float red[2][NW][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cpg = c >> 5;
+  const int rpp = T / vu;                               // rows per pass; threads >= rpp * vu idle
+  const int col = tid % vu, r0 = tid / vu;
+  const bool live = tid < rpp * vu;
+  const int unit = blockIdx.x, sample = blockIdx.y;
+  const int ch0 = (unit * vu + col) * 8;                // first channel of this thread's vector
+  const int ug0 = (unit * vu * 8) / cpg;                // first group of the unit
+  const bf16_t* xs = x + (int64_t)sample * rows * c + ch0;
+  bf16_t* ys = y + (int64_t)sample * rows * c + ch0;
+  int gl[8];                                            // group (local to the unit, 0..3) of each of the 8 channels
+#pragma unroll
+  for (int e = 0; e < 8; ++e) gl[e] = (ch0 + e) / cpg - ug0;
+
+  u32x4 v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int r = r0 + i * rpp;
+    v[i] = (live && r < rows) ? *reinterpret_cast<const u32x4*>(xs + (int64_t)r * c) : u32x4{0u, 0u, 0u, 0u};
+  }
+  // block-wide sum of a per-channel quantity, per group: lane -> 4 group slots -> wave -> LDS -> everyone
+  auto group_sums = [&](const float (&pc)[8], int slot, float (&out)[4]) {
+    float g4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) g4[g] += (gl[e] == g) ? pc[e] : 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) g4[g] = wave_sum(g4[g]);
+    if (lane == 0) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) red[slot][wave][g] = g4[g];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += red[slot][w][g];
+      out[g] = t;
+    }
+  };
+  float pc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    float f[8];
+    unpack8(v[i], f);                                   // rows beyond the slab hold zeros: they add nothing
+#pragma unroll
+    for (int e = 0; e < 8; ++e) pc[e] += f[e];
+  }
+  float gs[4];
+  group_sums(pc, 0, gs);
+  const float inv_cnt = 1.0f / ((float)rows * (float)cpg);
+  float mean_e[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float m = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) m = (gl[e] == g) ? gs[g] * inv_cnt : m;
+    mean_e[e] = m;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) pc[e] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int r = r0 + i * rpp;
+    gn_opaque(v[i]);
+    if (live && r < rows) {
+      float f[8];
+      unpack8(v[i], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = f[e] - mean_e[e]; pc[e] += d * d; }
+    }
+  }
+  float gq[4];
+  group_sums(pc, 1, gq);
+  float sc[8], sh[8];
+  if (live) {
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + ch0), g1 = *reinterpret_cast<const f32x4*>(gamma + ch0 + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + ch0), b1 = *reinterpret_cast<const f32x4*>(beta + ch0 + 4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float var = 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) var = (gl[e] == g) ? gq[g] * inv_cnt : var;
+      const float a = rsqrtf(var + eps) * (e < 4 ? g0[e] : g1[e - 4]);
+      sc[e] = a;
+      sh[e] = (e < 4 ? b0[e] : b1[e - 4]) - mean_e[e] * a;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int r = r0 + i * rpp;
+      gn_opaque(v[i]);
+      if (r < rows) {
+        float f[8];
+        unpack8(v[i], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float t = f[e] * sc[e] + sh[e];
+          f[e] = silu ? silu_f(t) : t;
+        }
+        *reinterpret_cast<u32x4*>(ys + (int64_t)r * c) = pack8(f);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // LayerNorm: a wave normalises R rows at a time, each row held in registers (NV vectors of 8 per lane), true
 // two-pass variance.  R > 1 for the narrow rows (C <= 512: R = 4, C <= 1024: R = 2) puts several row loads in
 // flight per wave -- at C = 320 only 40 of the 64 lanes carry data, so one row per wave left the kernel
@@ -349,9 +475,38 @@ extern "C" int tc_groupnorm(const tc_bf16* x, tc_bf16* y, const float* gamma, co
   if (!tc_aligned16(x) || !tc_aligned16(y)) return TC_EALIGN;
   if (workspace_bytes < tc_groupnorm_workspace(samples, rows, c)) return TC_EWORKSPACE;
   if (samples > 65535) return TC_ESHAPE;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  {
+    // single-pass kernel when a (sample, unit) slab fits the registers of one block (TC_GN_ONEPASS=0: never)
+    static const bool onepass = [] { const char* e = getenv("TC_GN_ONEPASS"); return !(e && e[0] == '0'); }();
+    const int cpg = c / 32;
+    int u = cpg;
+    while (u % 8) u += cpg;                                       // lcm(8, cpg) = U channels per unit
+    const int vu = u / 8, gu = u / cpg;
+    if (onepass && (c % u) == 0 && gu <= 4 && vu <= 64 && tc_aligned16(gamma) && tc_aligned16(beta)) {
+      const int64_t nvec = (int64_t)rows * vu;
+      const dim3 grid(c / u, samples);
+      const bf16_t* xb = reinterpret_cast<const bf16_t*>(x);
+      bf16_t* yb = reinterpret_cast<bf16_t*>(y);
+      auto fits = [&](int t, int nv) { return (int64_t)((rows + t / vu - 1) / (t / vu)) <= nv; };
+      // measured (profiles/r02_gn_onepass_ab.txt): wins 13-32 % where the grid fills the chip (per-frame norms of levels
+      // 1-3) or the tensor is tiny (level-3 clip-wide, 3 MB); LOSES with 64 blocks on a 13 MB tensor (level-2
+      // clip-wide: 20 -> 31 us) and is neutral at level 0 (a 512-thread / 26-vector instance: dropped)
+      const int64_t nblk = (int64_t)(c / u) * samples;
+      const int64_t bytes = nvec * 16 * samples * (c / u);
+      bool done = nblk >= 128 || bytes <= (4 << 20);
+      if (!done) {}
+      else if (fits(256, 4)) hipLaunchKernelGGL((gn_onepass_kernel<256, 4>), grid, dim3(256), 0, s, xb, yb, gamma, beta, rows, c, vu, eps, silu);
+      else if (fits(256, 13)) hipLaunchKernelGGL((gn_onepass_kernel<256, 13>), grid, dim3(256), 0, s, xb, yb, gamma, beta, rows, c, vu, eps, silu);
+      else done = false;
+      if (done) {
+        TC_LAUNCH_CHECK();
+        return TC_OK;
+      }
+    }
+  }
   int nch, cr;
   gn_chunking(samples, rows, &nch, &cr);
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   float* part = reinterpret_cast<float*>(workspace);
   float* stats = part + (int64_t)samples * nch * 64;
   dim3 grid(nch, samples), block(GN_THREADS);
