@@ -52,7 +52,24 @@ def main():
         gr.replay()
     torch.cuda.synchronize()
     assert torch.isfinite(y).all()
-    print(f"[health] hipGraph replay ok; all checks passed in {time.time() - t0:.1f} s", flush=True)
+    print("[health] hipGraph replay ok", flush=True)
+    # a few seconds of what the bench looks like to the box: sustained bf16 GEMMs at full power, allocator churn
+    # (hundreds of 50-700 MB tensors created and freed), host<->device traffic in between
+    m = torch.randn(8192, 8192, device=dev).to(torch.bfloat16)
+    t_end = time.time() + 4.0
+    n = 0
+    while time.time() < t_end:
+        bufs = [torch.empty((81920 * (1 + i % 4), 320), device=dev, dtype=torch.bfloat16).normal_() for i in range(6)]
+        for b in bufs:
+            acc = m @ m
+            b.mul_(0.5)
+        h = bufs[0][:4096].cpu()
+        assert torch.isfinite(h.float()).all()
+        del bufs
+        n += 1
+    torch.cuda.synchronize()
+    assert torch.isfinite(acc.float()).all()
+    print(f"[health] sustained load ok ({n} rounds); all checks passed in {time.time() - t0:.1f} s", flush=True)
 
 
 if __name__ == "__main__":

@@ -12,8 +12,8 @@ for s in "$@"; do
     bench)   timeout 1500 python bench.py --steps 2 --warmup 1 > $OUT/bench_full.log 2>&1 ;;
     benchq)  timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_quick.log 2>&1 ;;
     benchbd) timeout 1500 python bench.py --steps 1 --warmup 1 --batched-decode 4 --no-cpu-baseline --no-roofline > $OUT/bench_batched_decode.log 2>&1 ;;
-    profdec) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/profdec -o prof -- python $OLDPWD/bench.py --steps 1 --warmup 1 --ddim-steps 1 --no-cpu-baseline --no-roofline > $OLDPWD/$OUT/profdec.log 2>&1; python $OLDPWD/scripts/prof_summary.py "$(find /tmp/profdec -name '*.db' | head -1)" 40 > $OLDPWD/$OUT/profdec_stats.txt 2>> $OLDPWD/$OUT/profdec.log) ;;
-    prof)    (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d /tmp/profclip -o prof -- python $OLDPWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $OLDPWD/$OUT/prof.log 2>&1; python $OLDPWD/scripts/prof_summary.py "$(find /tmp/profclip -name '*.db' | head -1)" 40 > $OLDPWD/$OUT/prof_stats.txt 2>> $OLDPWD/$OUT/prof.log) ;;
+    profdec) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/profdec -o prof -- python $OLDPWD/bench.py --no-retry --steps 1 --warmup 1 --ddim-steps 1 --no-cpu-baseline --no-roofline > $OLDPWD/$OUT/profdec.log 2>&1; python $OLDPWD/scripts/prof_summary.py "$(find /tmp/profdec -name '*.db' | head -1)" 40 > $OLDPWD/$OUT/profdec_stats.txt 2>> $OLDPWD/$OUT/profdec.log) ;;
+    prof)    (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d /tmp/profclip -o prof -- python $OLDPWD/bench.py --no-retry --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $OLDPWD/$OUT/prof.log 2>&1; python $OLDPWD/scripts/prof_summary.py "$(find /tmp/profclip -name '*.db' | head -1)" 40 > $OLDPWD/$OUT/prof_stats.txt 2>> $OLDPWD/$OUT/prof.log) ;;
     pmcattn) bash scripts/pmc_run.sh attn scripts/pmc_attn.py attn ;;
     probe)   (cd /tmp && hipcc --offload-arch=gfx950 -O2 $OLDPWD/scripts/probes/tr_probe.hip -o /tmp/tr_probe 2>/dev/null && /tmp/tr_probe) > $OUT/tr_probe.txt 2>&1 ;;
     gemmbench) timeout 600 python scripts/gemm_bench.py > $OUT/gemm_bench.log 2>&1 ;;

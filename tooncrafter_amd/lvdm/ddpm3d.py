@@ -295,7 +295,21 @@ class LatentDiffusion(DDPM):
         if z.dim() != 5:
             raise NotImplementedError("decode_first_stage expects a (B, C, T, h, w) video latent")
         ref_context = kwargs.get("ref_context")
-        return self.first_stage_model.decoder.decode_clip(z, ref_context, scale=1.0 / float(self.scale_factor))
+        dec = self.first_stage_model.decoder
+        scale = 1.0 / float(self.scale_factor)
+        # the kernels address an activation with 31-bit byte offsets: the largest one of a decode (level 0: T * 8h * 8w
+        # rows x 128 channels bf16 per clip) bounds how many clips go through one call; more are decoded in groups
+        # (each group still has all T frames of its clips in ONE call)
+        b, _, t, h, w = z.shape
+        per_clip = t * (8 * h) * (8 * w) * int(getattr(dec, "ch", 128)) * 2
+        bmax = max(1, int(0x7fffff00 // max(per_clip, 1)))
+        if b <= bmax:
+            return dec.decode_clip(z, ref_context, scale=scale)
+        outs = []
+        for i in range(0, b, bmax):
+            refs = None if not ref_context else [r[i:i + bmax].contiguous() for r in ref_context]
+            outs.append(dec.decode_clip(z[i:i + bmax].contiguous(), refs, scale=scale))
+        return torch.cat(outs, 0)
 
 
 class LatentVisualDiffusion(LatentDiffusion):
