@@ -511,7 +511,7 @@ def main():
                                     "+ 14f re-decode + splice; a different clip every step") % (
                                         args.ddim_steps,
                                         "1 clip per GPU (BASELINE.json configs[1])" if bdec == 0 else
-                                        f"{bdec} clips per GPU decoded in one call, perframe_ae=False (BASELINE.json configs[3])"),
+                                        f"{bdec} clips per GPU through one decode_first_stage call, perframe_ae=False (BASELINE.json configs[3]; grouped so that no activation exceeds 2 GiB)"),
                        "clips_per_step": world * clips_per_step,
                        "parallelism": f"dp{world} (independent clips, one RCCL gather)"},
             "effective_tflops_per_gpu": round(TFLOP_CLIP * args.steps * clips_per_step / dt, 1) if args.ddim_steps == 50 else None,

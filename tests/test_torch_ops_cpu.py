@@ -1,0 +1,52 @@
+"""The TORCH_LIBRARY(tooncrafter) operator layer without a GPU: the library loads next to the kernel library, every
+operator is registered with the schema the Python wrapper uses, and the Meta implementations infer the output shapes
+and dtypes (what tracing / export would see).  Compute is covered by tests/test_gpu_torch_ops.py."""
+import pytest
+import torch
+
+from tooncrafter_amd import _lib
+
+
+@pytest.fixture(scope="module")
+def t():
+    from tooncrafter_amd import torch_ops
+    return torch_ops.load()
+
+
+def test_operator_namespace_and_abi(t):
+    assert int(t.abi_version()) == _lib.TC_ABI_VERSION
+    for name in ("gemm", "attention", "attention_temporal", "groupnorm", "layernorm", "ddim_step"):
+        op = getattr(t, name)
+        schema = str(op.default._schema)
+        assert schema.startswith(f"tooncrafter::{name}("), schema
+    assert "int[] conv" in str(t.gemm.default._schema) and "Tensor? k2" in str(t.attention.default._schema)
+
+
+def test_meta_kernels_infer_shapes(t):
+    bf = dict(dtype=torch.bfloat16, device="meta")
+    f32 = dict(dtype=torch.float32, device="meta")
+    a, w = torch.empty(81920, 320, **bf), torch.empty(960, 320, **bf)
+    assert t.gemm(a, w, None, None, None, 0, 0, 1.0, 1.0, False, []).shape == (81920, 960)
+    wg = torch.empty(2560, 320, **bf)                                            # GEGLU halves the columns
+    y = t.gemm(a, wg, torch.empty(2560, **f32), None, None, 0, 3, 1.0, 1.0, False, [])
+    assert y.shape == (81920, 1280) and y.dtype == torch.bfloat16
+    wc = torch.empty(320, 2880, **bf)                                            # 3x3 conv, stride 2: M from the geometry
+    conv = [1, 320, 32, 1, 40, 64, 20, 32, 2, 0, 1]
+    y = t.gemm(a, wc, None, None, None, 0, 0, 1.0, 1.0, True, conv)
+    assert y.shape == (32 * 20 * 32, 320) and y.dtype == torch.float32
+    q, kv = torch.empty(32 * 2560, 320, **bf), torch.empty(2 * 77, 320, **bf)
+    ki = torch.empty(32 * 16, 320, **bf)
+    assert t.attention(q, kv, kv, 32, 5, 2560, 77, 16, 0.125, ki, ki, 16, 1).shape == (32 * 2560, 320)
+    assert t.attention_temporal(torch.empty(2 * 16 * 40, 3 * 128, **bf), 2, 16, 40, 2, 0.125).shape == (2 * 16 * 40, 128)
+    x = torch.empty(5120, 1280, **bf)
+    g = torch.empty(1280, **f32)
+    assert t.groupnorm(x, g, g, 32, 160, 1e-5, True).shape == x.shape and t.layernorm(x, g, g, 1e-5).dtype == torch.bfloat16
+    lat = torch.empty(1, 4, 16, 40, 64, **f32)
+    xp, x0 = t.ddim_step(lat, lat, lat, lat, None, 7.5, 7.5, 0.7, 0.6, 0.8, 0.7, 0.5, 0.3, 0.98)
+    assert xp.shape == lat.shape and x0.shape == lat.shape
+
+
+def test_cpu_tensors_are_refused(t):
+    a, w = torch.zeros(8, 64, dtype=torch.bfloat16), torch.zeros(64, 64, dtype=torch.bfloat16)
+    with pytest.raises((RuntimeError, NotImplementedError)):                     # no CPU kernel is registered: no fallback
+        t.gemm(a, w, None, None, None, 0, 0, 1.0, 1.0, False, [])

@@ -54,6 +54,42 @@ def _lib_digest_matches(dig: str) -> bool:
         return False
 
 
+TORCH_LIB = os.path.join(HERE, "libtooncrafter_torch.so")
+TORCH_SRC = os.path.join(CSRC, "torch_ops.cpp")
+
+
+def build_torch_ops(force: bool = False, verbose: bool = True) -> str:
+    """The TORCH_LIBRARY(tooncrafter) operator layer (csrc/torch_ops.cpp): host C++ only, linked against the kernel
+    library and libtorch, built in-tree with the host compiler (no hipcc needed: it launches nothing itself)."""
+    import torch
+    from torch.utils import cpp_extension as ce
+    h = hashlib.sha256()
+    for p in (TORCH_SRC, os.path.join(ROOT, "include", "tooncrafter_hip.h")):
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(torch.__version__.encode())
+    dig = h.hexdigest()
+    stamp = TORCH_LIB + ".digest"
+    if not force and os.path.exists(TORCH_LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig \
+            and os.path.getmtime(TORCH_LIB) >= os.path.getmtime(LIB):
+        return TORCH_LIB
+    cxx = os.environ.get("CXX") or shutil.which("g++") or shutil.which("c++")
+    if not cxx:
+        raise RuntimeError("no host C++ compiler for the torch operator layer")
+    tlib = ce.library_paths()[0]
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
+           *["-I" + p for p in ce.include_paths()], "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
+           TORCH_SRC, "-o", TORCH_LIB, "-L" + tlib, "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_hip",
+           "-L" + HERE, "-ltooncrafter_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + tlib]
+    if verbose:
+        print("[build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(dig)
+    return TORCH_LIB
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     dig = _digest()
     if not force and _lib_digest_matches(dig):
@@ -86,3 +122,4 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    print(build_torch_ops(force="--force" in sys.argv))

@@ -1,0 +1,253 @@
+// PyTorch-ROCm custom-op layer over the C ABI (include/tooncrafter_hip.h):  TORCH_LIBRARY(tooncrafter, ...)
+//
+// The reference binds ATen / xformers operators from Python (utils/utils.py:27-42 instantiates lvdm classes whose
+// forward methods call torch ops); this registers the MI355X kernels as first-class torch operators instead:
+//   torch.ops.tooncrafter.gemm / attention / attention_temporal / groupnorm / layernorm / ddim_step
+// with (i) a CUDA(HIP)-key implementation that validates the tensors, allocates the result from the caching allocator,
+// picks up the CURRENT stream and calls the same extern "C" entry point the ctypes binding calls, and (ii) a Meta-key
+// implementation (shape / dtype inference only) so the ops can be traced, exported and shape-checked without a GPU.
+// Host C++ only: the kernels live in libtooncrafter_hip.so, which this library links.
+// Built by tooncrafter_amd/build.py (build_torch_ops) with the host compiler; selected with TC_BINDING=torch
+// (tooncrafter_amd/torch_ops.py).  The ctypes binding stays the default: DESIGN.md section 1 measures the two
+// launch paths as equivalent at these shapes.
+#include <ATen/ATen.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/library.h>
+
+#include <tuple>
+#include <vector>
+
+#include "tooncrafter_hip.h"
+
+namespace {
+
+using at::Tensor;
+using c10::optional;
+
+void* cur_stream() { return reinterpret_cast<void*>(c10::hip::getCurrentHIPStream().stream()); }
+
+void check_rc(int rc, const char* what) {
+  TORCH_CHECK(rc == 0, what, " failed with code ", rc,
+              rc < 0 ? " (TC_E*: -1 invalid, -2 alignment, -3 unsupported shape, -4 workspace)" : " (hipError_t)");
+}
+
+const tc_bf16* bf(const Tensor& t) { return reinterpret_cast<const tc_bf16*>(t.data_ptr()); }
+
+void check_rows(const Tensor& t, const char* name, at::ScalarType dt = at::kBFloat16) {
+  TORCH_CHECK(t.is_cuda(), name, ": expected a CUDA tensor (the product path is GPU-only)");
+  TORCH_CHECK(t.dim() == 2 && t.stride(1) == 1 && t.scalar_type() == dt, name,
+              ": expected a 2-D rows tensor with unit column stride and dtype ", dt);
+}
+
+// conv = [] (linear) or [kind (1 = 3x3, 2 = t3), cin, frames, t_len, h_in, w_in, h_out, w_out, stride, upsample, pad]
+struct GemmGeom { int64_t m, n, n_out, k; };
+GemmGeom gemm_geom(const Tensor& a, const Tensor& w, int64_t act, at::IntArrayRef conv) {
+  GemmGeom g;
+  g.n = w.size(0);
+  g.k = w.size(1);
+  g.n_out = act == TC_ACT_GEGLU ? g.n / 2 : g.n;
+  g.m = conv.empty() ? a.size(0) : conv[2] * conv[6] * conv[7];
+  return g;
+}
+
+Tensor gemm_cuda(const Tensor& a, const Tensor& w, const optional<Tensor>& bias, const optional<Tensor>& residual,
+                 const optional<Tensor>& row_bias, int64_t row_div, int64_t act, double alpha, double out_scale,
+                 bool out_f32, at::IntArrayRef conv) {
+  check_rows(a, "gemm: a");
+  check_rows(w, "gemm: w");
+  TORCH_CHECK(conv.empty() || conv.size() == 11, "gemm: conv must be empty or 11 integers");
+  const GemmGeom g = gemm_geom(a, w, act, conv);
+  Tensor out = at::empty({g.m, g.n_out}, a.options().dtype(out_f32 ? at::kFloat : at::kBFloat16));
+  TcGemmParams p = {};
+  p.a = bf(a); p.w = bf(w); p.c = out.data_ptr();
+  p.m = (int32_t)g.m; p.n = (int32_t)g.n; p.k = (int32_t)g.k;
+  p.lda = (int32_t)a.stride(0); p.ldw = (int32_t)w.stride(0); p.ldc = (int32_t)out.stride(0);
+  p.alpha = (float)alpha; p.out_scale = (float)out_scale; p.act = (int32_t)act; p.out_f32 = out_f32 ? 1 : 0;
+  p.batch = 1;
+  if (bias.has_value()) {
+    TORCH_CHECK(bias->is_cuda() && bias->scalar_type() == at::kFloat && bias->is_contiguous() && bias->numel() == g.n,
+                "gemm: bias must be a contiguous fp32 CUDA [N]");
+    p.bias = bias->data_ptr<float>();
+  }
+  if (row_bias.has_value()) {
+    check_rows(*row_bias, "gemm: row_bias", at::kFloat);
+    TORCH_CHECK(row_div > 0 && row_bias->size(1) == g.n && row_bias->size(0) * row_div >= g.m, "gemm: row_bias / row_div do not cover M");
+    p.row_bias = row_bias->data_ptr<float>(); p.ldrb = (int32_t)row_bias->stride(0); p.row_div = (int32_t)row_div;
+  }
+  if (residual.has_value()) {
+    check_rows(*residual, "gemm: residual");
+    TORCH_CHECK(residual->size(1) == g.n_out && residual->size(0) >= g.m, "gemm: residual shape mismatch");
+    p.residual = bf(*residual); p.ldr = (int32_t)residual->stride(0);
+  }
+  if (conv.empty()) {
+    p.gather = TC_GATHER_LINEAR;
+    TORCH_CHECK(a.size(1) >= g.k, "gemm: A has fewer columns than the weight's K");
+  } else {
+    p.gather = conv[0] == 1 ? TC_GATHER_CONV3x3 : TC_GATHER_CONVT3;
+    p.cin = (int32_t)conv[1]; p.frames = (int32_t)conv[2]; p.t_len = (int32_t)conv[3];
+    p.h_in = (int32_t)conv[4]; p.w_in = (int32_t)conv[5]; p.h_out = (int32_t)conv[6]; p.w_out = (int32_t)conv[7];
+    p.stride = (int32_t)conv[8]; p.upsample = (int32_t)conv[9]; p.pad = (int32_t)conv[10];
+    TORCH_CHECK(a.size(0) >= (int64_t)p.frames * p.h_in * p.w_in && a.size(1) >= p.cin, "gemm: conv source too small for its geometry");
+  }
+  Tensor ws;
+  const int64_t nbytes = tc_gemm_workspace(&p);
+  if (nbytes > 0) {
+    ws = at::empty({nbytes}, a.options().dtype(at::kByte));
+    p.workspace = ws.data_ptr(); p.workspace_bytes = nbytes;
+  }
+  check_rc(tc_gemm_bf16(&p, cur_stream()), "tc_gemm_bf16");
+  return out;
+}
+
+Tensor gemm_meta(const Tensor& a, const Tensor& w, const optional<Tensor>&, const optional<Tensor>&, const optional<Tensor>&,
+                 int64_t, int64_t act, double, double, bool out_f32, at::IntArrayRef conv) {
+  const GemmGeom g = gemm_geom(a, w, act, conv);
+  return at::empty({g.m, g.n_out}, a.options().dtype(out_f32 ? at::kFloat : at::kBFloat16));
+}
+
+Tensor attention_cuda(const Tensor& q, const Tensor& k, const Tensor& v, int64_t batch, int64_t heads, int64_t lq, int64_t lk,
+                      int64_t kv_bdiv, double scale, const optional<Tensor>& k2, const optional<Tensor>& v2, int64_t lk2,
+                      int64_t kv2_bdiv) {
+  check_rows(q, "attention: q"); check_rows(k, "attention: k"); check_rows(v, "attention: v");
+  const int64_t hd = heads * 64;
+  TORCH_CHECK(q.size(0) == batch * lq && q.size(1) == hd && k.size(1) == hd && v.size(1) == hd, "attention: head layout mismatch");
+  const int64_t kvb = (batch + kv_bdiv - 1) / kv_bdiv;
+  TORCH_CHECK(k.size(0) == kvb * lk && v.size(0) == kvb * lk, "attention: K/V rows != kv_batches * lk");
+  Tensor out = at::empty({batch * lq, hd}, q.options());
+  TcAttnParams p = {};
+  p.q = bf(q); p.k = bf(k); p.v = bf(v); p.o = reinterpret_cast<tc_bf16*>(out.data_ptr());
+  p.batch = (int32_t)batch; p.heads = (int32_t)heads; p.lq = (int32_t)lq; p.lk = (int32_t)lk;
+  p.q_ss = (int32_t)q.stride(0); p.k_ss = (int32_t)k.stride(0); p.v_ss = (int32_t)v.stride(0); p.o_ss = (int32_t)out.stride(0);
+  p.q_sb = lq * q.stride(0); p.k_sb = lk * k.stride(0); p.v_sb = lk * v.stride(0); p.o_sb = lq * out.stride(0);
+  p.kv_bdiv = (int32_t)kv_bdiv; p.scale = (float)scale;
+  if (k2.has_value()) {
+    TORCH_CHECK(v2.has_value() && lk2 > 0 && kv2_bdiv > 0, "attention: second K/V set incomplete");
+    check_rows(*k2, "attention: k2"); check_rows(*v2, "attention: v2");
+    const int64_t kvb2 = (batch + kv2_bdiv - 1) / kv2_bdiv;
+    TORCH_CHECK(k2->size(0) == kvb2 * lk2 && v2->size(0) == kvb2 * lk2 && k2->size(1) == hd && v2->size(1) == hd,
+                "attention: second K/V set must be [(batch / kv2_bdiv) * lk2, heads * 64]");
+    p.k2 = bf(*k2); p.v2 = bf(*v2); p.lk2 = (int32_t)lk2; p.kv2_bdiv = (int32_t)kv2_bdiv;
+    p.k2_ss = (int32_t)k2->stride(0); p.v2_ss = (int32_t)v2->stride(0);
+    p.k2_sb = lk2 * k2->stride(0); p.v2_sb = lk2 * v2->stride(0);
+  }
+  check_rc(tc_attn_d64(&p, cur_stream()), "tc_attn_d64");
+  return out;
+}
+
+Tensor attention_meta(const Tensor& q, const Tensor&, const Tensor&, int64_t batch, int64_t heads, int64_t lq, int64_t, int64_t,
+                      double, const optional<Tensor>&, const optional<Tensor>&, int64_t, int64_t) {
+  return at::empty({batch * lq, heads * 64}, q.options());
+}
+
+Tensor attention_temporal_cuda(const Tensor& qkv, int64_t b, int64_t t, int64_t hw, int64_t heads, double scale) {
+  check_rows(qkv, "attention_temporal: qkv");
+  TORCH_CHECK(qkv.is_contiguous() && qkv.size(0) == b * t * hw && qkv.size(1) == 3 * heads * 64,
+              "attention_temporal: qkv must be contiguous [b*t*hw, 3*heads*64]");
+  Tensor out = at::empty({b * t * hw, heads * 64}, qkv.options());
+  check_rc(tc_attn_temporal(bf(qkv), reinterpret_cast<tc_bf16*>(out.data_ptr()), (int32_t)b, (int32_t)t, (int32_t)hw,
+                            (int32_t)heads, (float)scale, cur_stream()), "tc_attn_temporal");
+  return out;
+}
+
+Tensor attention_temporal_meta(const Tensor& qkv, int64_t b, int64_t t, int64_t hw, int64_t heads, double) {
+  return at::empty({b * t * hw, heads * 64}, qkv.options());
+}
+
+void check_affine(const Tensor& g, const Tensor& b, int64_t c, const char* what) {
+  TORCH_CHECK(g.is_cuda() && b.is_cuda() && g.scalar_type() == at::kFloat && b.scalar_type() == at::kFloat &&
+              g.is_contiguous() && b.is_contiguous() && g.numel() == c && b.numel() == c, what, ": gamma / beta must be contiguous fp32 CUDA [C]");
+}
+
+Tensor groupnorm_cuda(const Tensor& x, const Tensor& gamma, const Tensor& beta, int64_t samples, int64_t rows, double eps, bool silu) {
+  check_rows(x, "groupnorm: x");
+  const int64_t c = x.size(1);
+  TORCH_CHECK(x.is_contiguous() && x.size(0) == samples * rows, "groupnorm: x must be contiguous [samples*rows, C]");
+  check_affine(gamma, beta, c, "groupnorm");
+  Tensor y = at::empty_like(x);
+  const int64_t nbytes = tc_groupnorm_workspace((int32_t)samples, (int32_t)rows, (int32_t)c);
+  Tensor ws = at::empty({nbytes > 16 ? nbytes : 16}, x.options().dtype(at::kByte));
+  check_rc(tc_groupnorm(bf(x), reinterpret_cast<tc_bf16*>(y.data_ptr()), gamma.data_ptr<float>(), beta.data_ptr<float>(),
+                        (int32_t)samples, (int32_t)rows, (int32_t)c, (float)eps, silu ? 1 : 0, ws.data_ptr(), nbytes, cur_stream()),
+           "tc_groupnorm");
+  return y;
+}
+
+Tensor layernorm_cuda(const Tensor& x, const Tensor& gamma, const Tensor& beta, double eps) {
+  check_rows(x, "layernorm: x");
+  TORCH_CHECK(x.is_contiguous(), "layernorm: x must be contiguous");
+  check_affine(gamma, beta, x.size(1), "layernorm");
+  Tensor y = at::empty_like(x);
+  check_rc(tc_layernorm(bf(x), reinterpret_cast<tc_bf16*>(y.data_ptr()), gamma.data_ptr<float>(), beta.data_ptr<float>(),
+                        (int32_t)x.size(0), (int32_t)x.size(1), (float)eps, cur_stream()), "tc_layernorm");
+  return y;
+}
+
+Tensor like_meta3(const Tensor& x, const Tensor&, const Tensor&, int64_t, int64_t, double, bool) { return at::empty_like(x); }
+Tensor like_meta_ln(const Tensor& x, const Tensor&, const Tensor&, double) { return at::empty_like(x); }
+
+std::tuple<Tensor, Tensor> ddim_step_cuda(const Tensor& x, const Tensor& e_cond, const optional<Tensor>& e_uncond,
+                                          const optional<Tensor>& noise, const optional<Tensor>& e_uncond_img, double cfg_scale,
+                                          double cfg_img, double guidance_rescale, double sqrt_ac, double sqrt_1m_ac,
+                                          double sqrt_a_prev, double dir_coef, double sigma, double x0_rescale) {
+  auto ok = [](const Tensor& t) { return t.is_cuda() && t.scalar_type() == at::kFloat && t.is_contiguous(); };
+  TORCH_CHECK(ok(x) && ok(e_cond) && (!e_uncond.has_value() || ok(*e_uncond)) && (!noise.has_value() || ok(*noise)) &&
+              (!e_uncond_img.has_value() || ok(*e_uncond_img)), "ddim_step: contiguous fp32 CUDA tensors");
+  Tensor x_prev = at::empty_like(x), x0 = at::empty_like(x);
+  TcDdimParams p = {};
+  p.x = x.data_ptr<float>(); p.e_cond = e_cond.data_ptr<float>();
+  p.e_uncond = e_uncond.has_value() ? e_uncond->data_ptr<float>() : nullptr;
+  p.noise = noise.has_value() ? noise->data_ptr<float>() : nullptr;
+  p.e_uncond_img = e_uncond_img.has_value() ? e_uncond_img->data_ptr<float>() : nullptr;
+  p.x_prev = x_prev.data_ptr<float>(); p.pred_x0 = x0.data_ptr<float>();
+  p.b = (int32_t)x.size(0); p.n = x.numel() / x.size(0);
+  p.cfg_scale = (float)cfg_scale; p.cfg_img = (float)cfg_img; p.guidance_rescale = (float)guidance_rescale;
+  p.sqrt_ac = (float)sqrt_ac; p.sqrt_1m_ac = (float)sqrt_1m_ac; p.sqrt_a_prev = (float)sqrt_a_prev;
+  p.dir_coef = (float)dir_coef; p.sigma = (float)sigma; p.x0_rescale = (float)x0_rescale;
+  const int64_t nbytes = tc_ddim_workspace(p.b);
+  Tensor ws = at::empty({nbytes > 16 ? nbytes : 16}, x.options().dtype(at::kByte));
+  check_rc(tc_ddim_step(&p, ws.data_ptr(), nbytes, cur_stream()), "tc_ddim_step");
+  return std::make_tuple(x_prev, x0);
+}
+
+std::tuple<Tensor, Tensor> ddim_step_meta(const Tensor& x, const Tensor&, const optional<Tensor>&, const optional<Tensor>&,
+                                          const optional<Tensor>&, double, double, double, double, double, double, double, double, double) {
+  return std::make_tuple(at::empty_like(x), at::empty_like(x));
+}
+
+}  // namespace
+
+TORCH_LIBRARY(tooncrafter, m) {
+  m.def("gemm(Tensor a, Tensor w, Tensor? bias, Tensor? residual, Tensor? row_bias, int row_div, int act, float alpha, "
+        "float out_scale, bool out_f32, int[] conv) -> Tensor");
+  m.def("attention(Tensor q, Tensor k, Tensor v, int batch, int heads, int lq, int lk, int kv_bdiv, float scale, "
+        "Tensor? k2, Tensor? v2, int lk2, int kv2_bdiv) -> Tensor");
+  m.def("attention_temporal(Tensor qkv, int b, int t, int hw, int heads, float scale) -> Tensor");
+  m.def("groupnorm(Tensor x, Tensor gamma, Tensor beta, int samples, int rows, float eps, bool silu) -> Tensor");
+  m.def("layernorm(Tensor x, Tensor gamma, Tensor beta, float eps) -> Tensor");
+  m.def("ddim_step(Tensor x, Tensor e_cond, Tensor? e_uncond, Tensor? noise, Tensor? e_uncond_img, float cfg_scale, "
+        "float cfg_img, float guidance_rescale, float sqrt_ac, float sqrt_1m_ac, float sqrt_a_prev, float dir_coef, "
+        "float sigma, float x0_rescale) -> (Tensor, Tensor)");
+  m.def("abi_version() -> int");
+}
+
+TORCH_LIBRARY_IMPL(tooncrafter, CUDA, m) {
+  m.impl("gemm", gemm_cuda);
+  m.impl("attention", attention_cuda);
+  m.impl("attention_temporal", attention_temporal_cuda);
+  m.impl("groupnorm", groupnorm_cuda);
+  m.impl("layernorm", layernorm_cuda);
+  m.impl("ddim_step", ddim_step_cuda);
+}
+
+TORCH_LIBRARY_IMPL(tooncrafter, Meta, m) {
+  m.impl("gemm", gemm_meta);
+  m.impl("attention", attention_meta);
+  m.impl("attention_temporal", attention_temporal_meta);
+  m.impl("groupnorm", like_meta3);
+  m.impl("layernorm", like_meta_ln);
+  m.impl("ddim_step", ddim_step_meta);
+}
+
+TORCH_LIBRARY_IMPL(tooncrafter, CompositeExplicitAutograd, m) {
+  m.impl("abi_version", []() -> int64_t { return tc_abi_version(); });
+}

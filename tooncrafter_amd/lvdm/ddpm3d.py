@@ -297,11 +297,12 @@ class LatentDiffusion(DDPM):
         ref_context = kwargs.get("ref_context")
         dec = self.first_stage_model.decoder
         scale = 1.0 / float(self.scale_factor)
-        # the kernels address an activation with 31-bit byte offsets: the largest one of a decode (level 0: T * 8h * 8w
-        # rows x 128 channels bf16 per clip) bounds how many clips go through one call; more are decoded in groups
-        # (each group still has all T frames of its clips in ONE call)
+        # the kernels address an activation with 31-bit byte offsets: the largest one of a decode (level 0 input of the
+        # first block after the upsample: T * 8h * 8w rows x 2 ch channels bf16 = 1.34 GB per 16-frame 320x512 clip)
+        # bounds how many clips go through one call; more are decoded in groups (each group still has all T frames
+        # of its clips in ONE call, which is what the dual-reference fusion needs)
         b, _, t, h, w = z.shape
-        per_clip = t * (8 * h) * (8 * w) * int(getattr(dec, "ch", 128)) * 2
+        per_clip = t * (8 * h) * (8 * w) * 2 * int(getattr(dec, "ch", 128)) * 2
         bmax = max(1, int(0x7fffff00 // max(per_clip, 1)))
         if b <= bmax:
             return dec.decode_clip(z, ref_context, scale=scale)

@@ -356,7 +356,12 @@ _backend = None
 def backend():
     global _backend
     if _backend is None:
-        _backend = HipOps()       # raises if libtooncrafter_hip.so is missing: no fallback
+        import os
+        if os.environ.get("TC_BINDING", "ctypes") == "torch":      # the TORCH_LIBRARY op layer over the same C ABI
+            from .torch_ops import TorchLibOps
+            _backend = TorchLibOps()
+        else:
+            _backend = HipOps()   # raises if libtooncrafter_hip.so is missing: no fallback
     return _backend
 
 

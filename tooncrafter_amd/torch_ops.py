@@ -1,0 +1,88 @@
+"""PyTorch-ROCm custom-op binding of the hot path: `torch.ops.tooncrafter.*` (csrc/torch_ops.cpp, TORCH_LIBRARY).
+
+The same `extern "C"` entry points as the ctypes binding (ops.HipOps), registered as torch operators with CUDA(HIP)
+and Meta implementations: current-stream pickup and output allocation happen in C++, and the ops can be shape-checked
+/ traced on the `meta` device without a GPU.  `TorchLibOps` is a drop-in for `HipOps`; select it with
+`TC_BINDING=torch` (or `ops.set_backend(TorchLibOps())`).  Calls that use features the functional op schema does not
+carry (an explicit `out=` buffer, batched GEMMs, accumulate) go through the inherited ctypes methods.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE
+from .ops import HipOps
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libtooncrafter_torch.so")
+_loaded = False
+
+
+def load():
+    """Register the `tooncrafter` operator namespace (idempotent).  Raises if the library is missing."""
+    global _loaded
+    if _loaded:
+        return torch.ops.tooncrafter
+    if not os.path.exists(LIB_PATH):
+        raise _lib.TooncrafterHipError(f"{LIB_PATH} not found: build it with `python -m tooncrafter_amd.build`")
+    torch.ops.load_library(LIB_PATH)
+    if int(torch.ops.tooncrafter.abi_version()) != _lib.TC_ABI_VERSION:
+        raise _lib.TooncrafterHipError("libtooncrafter_torch.so was built against another ABI version")
+    _loaded = True
+    return torch.ops.tooncrafter
+
+
+def conv_list(conv):
+    """ops.gemm's `conv` dict -> the 11-integer form of the op schema ([] = linear)."""
+    if conv is None:
+        return []
+    return [1 if conv["kind"] == "3x3" else 2, conv["cin"], conv["frames"], conv.get("t_len", 1),
+            conv.get("h_in", conv["h_out"]), conv.get("w_in", conv["w_out"]), conv["h_out"], conv["w_out"],
+            conv.get("stride", 1), 1 if conv.get("upsample", False) else 0, conv.get("pad", 1)]
+
+
+class TorchLibOps(HipOps):
+    """HipOps with the arithmetic operators dispatched through `torch.ops.tooncrafter`."""
+
+    name = "hip"          # the same kernels: callers that assert the HIP backend see it as such
+    binding = "torch"
+
+    def __init__(self):
+        super().__init__()
+        self.t = load()
+
+    def gemm(self, a, w, bias=None, *, act=ACT_NONE, residual=None, row_bias=None, row_div=0, alpha=1.0, out_scale=1.0,
+             out=None, out_f32=False, conv=None, batch=1, stride_a=0, stride_w=0, stride_c=0, m=None):
+        if out is not None or batch != 1 or m is not None:
+            return super().gemm(a, w, bias, act=act, residual=residual, row_bias=row_bias, row_div=row_div, alpha=alpha,
+                                out_scale=out_scale, out=out, out_f32=out_f32, conv=conv, batch=batch, stride_a=stride_a,
+                                stride_w=stride_w, stride_c=stride_c, m=m)
+        return self.t.gemm(a, w, bias, residual, row_bias, int(row_div), int(act), float(alpha), float(out_scale),
+                           bool(out_f32), conv_list(conv))
+
+    def attention(self, q, k, v, *, batch, heads, lq, lk, kv_bdiv=1, out=None, accumulate=False, scale=None,
+                  k2=None, v2=None, lk2=0, kv2_bdiv=1):
+        if out is not None or accumulate:
+            return super().attention(q, k, v, batch=batch, heads=heads, lq=lq, lk=lk, kv_bdiv=kv_bdiv, out=out,
+                                     accumulate=accumulate, scale=scale, k2=k2, v2=v2, lk2=lk2, kv2_bdiv=kv2_bdiv)
+        return self.t.attention(q, k, v, batch, heads, lq, lk, kv_bdiv, float(64 ** -0.5 if scale is None else scale),
+                                k2, v2, int(lk2), int(kv2_bdiv))
+
+    def attention_temporal(self, qkv, *, b, t, hw, heads, scale=None):
+        return self.t.attention_temporal(qkv, b, t, hw, heads, float(64 ** -0.5 if scale is None else scale))
+
+    def groupnorm(self, x, gamma, beta, *, samples, rows, eps, silu=False):
+        return self.t.groupnorm(x, gamma, beta, samples, rows, float(eps), bool(silu))
+
+    def layernorm(self, x, gamma, beta, eps=1e-5):
+        return self.t.layernorm(x, gamma, beta, float(eps))
+
+    def ddim_step(self, x, e_cond, e_uncond, noise, *, cfg_scale, guidance_rescale, sqrt_ac, sqrt_1m_ac, sqrt_a_prev,
+                  dir_coef, sigma, x0_rescale, want_x0=True, e_uncond_img=None, cfg_img=None):
+        xp, x0 = self.t.ddim_step(x, e_cond, e_uncond, noise, e_uncond_img, float(cfg_scale),
+                                  float(cfg_scale if cfg_img is None else cfg_img), float(guidance_rescale), float(sqrt_ac),
+                                  float(sqrt_1m_ac), float(sqrt_a_prev), float(dir_coef), float(sigma), float(x0_rescale))
+        return xp, (x0 if want_x0 else None)
