@@ -427,6 +427,8 @@ def main():
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--batched-decode", type=int, default=0, metavar="B",
                     help="configs[3]: B clips per GPU per step, decoded in one call (perframe_ae=False)")
+    ap.add_argument("--fp8", action="store_true",
+                    help="configs[4]: MXFP8 (e4m3 + E8M0 block scales) operands on the eligible GEMMs / convolutions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
@@ -434,6 +436,8 @@ def main():
     ap.add_argument("--no-retry", action="store_true", help="run in this process; no supervised retry")
     args = ap.parse_args()
 
+    if args.fp8:
+        os.environ["TC_FP8"] = os.environ.get("TC_FP8", "1")      # read when the operator backend is created
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
     if args.launcher_selftest:
@@ -506,10 +510,13 @@ def main():
             "metric": "interpolated frames/sec, 512x320x16f DDIM-50", "value": round(frames / dt, 4),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "bf16" if not args.fp8 else "fp8 e4m3 with E8M0 block scales (MXFP8) on the eligible GEMM operands, fp32 accumulate; bf16 elsewhere",
+            "data": "synthetic",
             "config": {"workload": ("ToonCrafter_512 320x512x16f ddim_steps=%d CFG 7.5 bf16, %s; sampler + 16f decode "
                                     "+ 14f re-decode + splice; a different clip every step") % (
                                         args.ddim_steps,
+                                        "1 clip per GPU, MXFP8 GEMM path (BASELINE.json configs[4])" if args.fp8 and bdec == 0 else
                                         "1 clip per GPU (BASELINE.json configs[1])" if bdec == 0 else
                                         f"{bdec} clips per GPU through one decode_first_stage call, perframe_ae=False (BASELINE.json configs[3]; grouped so that no activation exceeds 2 GiB)"),
                        "clips_per_step": world * clips_per_step,
@@ -519,6 +526,8 @@ def main():
             if args.ddim_steps == 50 else None,
             "output_finite": finite,
         }
+        if args.fp8:
+            result["fp8_gemm_calls"] = dict(ops.backend().fp8_calls)
         if STAGE_EVENTS:
             acc = {}
             for name, a, b in STAGE_EVENTS:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TC_ABI_VERSION 6
+#define TC_ABI_VERSION 7
 
 enum {
   TC_OK = 0,
@@ -96,6 +96,28 @@ typedef struct TcGemmParams {
 int tc_gemm_bf16(const TcGemmParams* p, void* stream);
 /* bytes of TcGemmParams.workspace this problem would use (0: it is not a split-K candidate) */
 int64_t tc_gemm_workspace(const TcGemmParams* p);
+
+/* ABI 7 -- MX block-scaled fp8 GEMM (BASELINE.json configs[4]: the CDNA4 fp8 MFMA GEMM path).
+ * Operands are OCP MX "MXFP8": e4m3 elements with one E8M0 (power-of-two) scale per 32 consecutive K
+ * elements of a row (OCP Microscaling Formats v1.0 section 5.1/6.3: shared exponent = floor(log2(amax)) - 8,
+ * elements = RNE(x / 2^shared) saturated to +-448).  The reference has no fp8 path; the tensors this
+ * replaces are the same nn.Linear / nn.Conv2d / nn.Conv3d operands as tc_gemm_bf16 above, and the parity
+ * oracle is oracle/mx.py (exact restatement of the quantiser + fp32 matmul of the dequantised operands). */
+typedef struct TcGemmMxParams {
+  TcGemmParams g;        /* as for tc_gemm_bf16, except: a / w point to fp8 e4m3 BYTES, lda / ldw / stride_a /
+                            stride_w are in elements (= bytes, multiples of 16), k and cin multiples of 32 (linear)
+                            / 64 (taps); c, bias, row_bias, residual and the epilogue are unchanged (bf16 / fp32);
+                            workspace is unused (no split-K), batch must be 1 */
+  const uint8_t* a_scale; /* E8M0 [source rows, lda_s]: byte j of a row scales its K elements [32 j, 32 j + 32) */
+  const uint8_t* w_scale; /* E8M0 [n, ldw_s] */
+  int32_t lda_s, ldw_s;   /* leading dimensions of the scale matrices in bytes (multiples of 4; >= ceil(k / 128) * 4
+                             for w and linear a, >= cin / 32 for a convolution source) */
+} TcGemmMxParams;
+int tc_gemm_mxfp8(const TcGemmMxParams* p, void* stream);
+/* bf16 rows [rows, ld] (first k columns, k % 32 == 0) -> e4m3 bytes q[rows, ldq] + E8M0 scales s[rows, lds];
+ * scale columns [k / 32, lds) are zero-filled so a K tail of the GEMM reads finite scales. */
+int tc_quant_mxfp8(const tc_bf16* x, int64_t rows, int32_t k, int32_t ld, uint8_t* q, int32_t ldq,
+                   uint8_t* s, int32_t lds, void* stream);
 
 typedef struct TcAttnParams {
   const tc_bf16* q; const tc_bf16* k; const tc_bf16* v; tc_bf16* o;

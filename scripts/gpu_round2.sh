@@ -16,6 +16,10 @@ for s in "$@"; do
     prof)    (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d /tmp/profclip -o prof -- python $OLDPWD/bench.py --no-retry --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $OLDPWD/$OUT/prof.log 2>&1; python $OLDPWD/scripts/prof_summary.py "$(find /tmp/profclip -name '*.db' | head -1)" 40 > $OLDPWD/$OUT/prof_stats.txt 2>> $OLDPWD/$OUT/prof.log) ;;
     pmcattn) bash scripts/pmc_run.sh attn scripts/pmc_attn.py attn ;;
     probe)   (cd /tmp && hipcc --offload-arch=gfx950 -O2 $OLDPWD/scripts/probes/tr_probe.hip -o /tmp/tr_probe 2>/dev/null && /tmp/tr_probe) > $OUT/tr_probe.txt 2>&1 ;;
+    fp8)     timeout 900 python -m pytest tests/test_gpu_fp8.py tests/test_gpu_fullsize.py -m gpu -q -s -p no:cacheprovider -k "fp8 or mx or quantiser or ineligible" > $OUT/fp8_tests.log 2>&1 ;;
+    benchfp8) timeout 900 python bench.py --fp8 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/bench_fp8.log 2>&1
+              timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/bench_bf16_same_box.log 2>&1 ;;
+    mxbench) timeout 300 python scripts/mx_bench.py > $OUT/mx_bench.txt 2>&1 ;;
     gemmbench) timeout 600 python scripts/gemm_bench.py > $OUT/gemm_bench.log 2>&1 ;;
     attncheck) timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_guard.py tests/test_gpu_properties.py -m gpu -q -p no:cacheprovider -k "attention" > $OUT/attn_check.log 2>&1
                if [ $? -ne 0 ]; then echo "DMA attention FAILED parity: falling back to TC_ATTN_STAGE=reg for the rest of this visit" | tee -a $OUT/round2.log; export TC_ATTN_STAGE=reg; fi ;;

@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libtooncrafter_hip.so")
 
-TC_ABI_VERSION = 6
+TC_ABI_VERSION = 7
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_GEGLU = 0, 1, 2, 3
 GATHER_LINEAR, GATHER_CONV3x3, GATHER_CONVT3 = 0, 1, 2
 
@@ -35,6 +35,11 @@ class TcGemmParams(C.Structure):
         ("stride_a", C.c_int64), ("stride_w", C.c_int64), ("stride_c", C.c_int64),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
+
+
+class TcGemmMxParams(C.Structure):
+    _fields_ = [("g", TcGemmParams), ("a_scale", C.c_void_p), ("w_scale", C.c_void_p),
+                ("lda_s", C.c_int32), ("ldw_s", C.c_int32)]
 
 
 class TcAttnParams(C.Structure):
@@ -65,6 +70,9 @@ class TcDdimParams(C.Structure):
 SYMBOLS = {
     "tc_gemm_bf16": (C.c_int, [C.POINTER(TcGemmParams), C.c_void_p]),
     "tc_gemm_workspace": (C.c_int64, [C.POINTER(TcGemmParams)]),
+    "tc_gemm_mxfp8": (C.c_int, [C.POINTER(TcGemmMxParams), C.c_void_p]),
+    "tc_quant_mxfp8": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                 C.c_void_p]),
     "tc_attn_d64": (C.c_int, [C.POINTER(TcAttnParams), C.c_void_p]),
     "tc_attn_temporal": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_float, C.c_void_p]),

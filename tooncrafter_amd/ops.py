@@ -22,7 +22,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_SILU, GATHER_CONV3x3, GATHER_CONVT3,
-                   GATHER_LINEAR, TcAttnParams, TcDdimParams, TcGemmParams)
+                   GATHER_LINEAR, TcAttnParams, TcDdimParams, TcGemmMxParams, TcGemmParams)
 
 BF16 = torch.bfloat16
 
@@ -65,8 +65,19 @@ class HipOps:
     name = "hip"
 
     def __init__(self):
+        import os
         self.lib = _lib.load()
         self._ws = {}
+        # BASELINE.json configs[4]: TC_FP8=1 routes the eligible GEMMs (see _fp8_eligible) through MXFP8 operands --
+        # weights quantised once, activations by tc_quant_mxfp8 in front of each GEMM.  TC_FP8=conv|linear narrows it.
+        mode = os.environ.get("TC_FP8", "0").lower()
+        self.fp8 = None if mode in ("0", "", "off") else ("all" if mode in ("1", "on", "all") else mode)
+        self.fp8_min_k = int(os.environ.get("TC_FP8_MIN_K", "640"))
+        self.fp8_min_n = int(os.environ.get("TC_FP8_MIN_N", "1280"))
+        self.fp8_max_cin = int(os.environ.get("TC_FP8_MAX_CIN", "1280"))
+        self.fp8_min_m = 1024
+        self.fp8_calls = {"mx": 0, "bf16": 0}
+        self._wq = {}
 
     # ------------------------------------------------------------------ workspace
     def _workspace(self, nbytes: int, device) -> torch.Tensor:
@@ -144,12 +155,67 @@ class HipOps:
         p.act, p.out_f32 = act, 1 if out_f32 else 0
         p.batch = batch
         p.stride_a, p.stride_w, p.stride_c = stride_a, stride_w, stride_c
+        if self.fp8 is not None:
+            if self._fp8_eligible(p, conv is not None, n_out, batch):
+                self.fp8_calls["mx"] += 1
+                self._gemm_mx(p, a, w)
+                return out
+            self.fp8_calls["bf16"] += 1
         nbytes = self.lib.tc_gemm_workspace(C.byref(p))          # > 0 only for split-K candidates (low-res layers)
         if nbytes > 0:
             ws = self._workspace(nbytes, a.device)
             p.workspace, p.workspace_bytes = ws.data_ptr(), nbytes
         _lib.check(self.lib.tc_gemm_bf16(C.byref(p), _stream()), "tc_gemm_bf16")
         return out
+
+    # ------------------------------------------------------------------ MXFP8 GEMM path (configs[4])
+    def quant_mxfp8(self, x, k=None):
+        """bf16 rows [R, >=k] -> (e4m3 bytes [R, k], E8M0 scales [R, ceil(k/128)*4]); one scale per 32 K elements."""
+        x = _rows_view(x)
+        k = x.shape[1] if k is None else k
+        if k % 32 or x.shape[1] < k:
+            raise ValueError(f"quant_mxfp8: k = {k} must be a multiple of 32 and <= {x.shape[1]} columns")
+        rows, lds = x.shape[0], (k + 127) // 128 * 4
+        q = torch.empty((rows, k), dtype=torch.uint8, device=x.device)
+        sc = torch.empty((rows, lds), dtype=torch.uint8, device=x.device)
+        _lib.check(self.lib.tc_quant_mxfp8(x.data_ptr(), rows, k, x.stride(0), q.data_ptr(), q.stride(0),
+                                           sc.data_ptr(), lds, _stream()), "tc_quant_mxfp8")
+        return q, sc
+
+    def _weight_mx(self, w):
+        """Quantised copy of a packed weight matrix, made once per weight tensor (held while the tensor lives)."""
+        import weakref
+        ent = self._wq.get(id(w))
+        if ent is None or ent[0]() is not w or ent[1] != w._version:
+            q, sc = self.quant_mxfp8(w if w.stride(0) % 8 == 0 else w.contiguous())
+            ent = (weakref.ref(w), w._version, q, sc)
+            if id(w) not in self._wq:
+                weakref.finalize(w, self._wq.pop, id(w), None)
+            self._wq[id(w)] = ent
+        return ent[2], ent[3]
+
+    def _fp8_eligible(self, p, is_conv, n_out, batch) -> bool:
+        if batch != 1 or n_out % 8 or p.k % 32 or p.m < self.fp8_min_m:
+            return False
+        # measured (profiles/r02_mx_gemm_bench.txt): with the activation quantiser in front, fp8 pays on the 3x3 /
+        # temporal convolutions up to cin = 1280 (one quantisation feeds 9 / 3 taps) and on linear layers whose N is
+        # large against K (qkv, GEGLU); short-K or narrow-N linear layers lose to the extra pass and stay bf16
+        if is_conv:
+            return self.fp8 in ("all", "conv") and p.cin % 64 == 0 and p.cin <= self.fp8_max_cin
+        return self.fp8 in ("all", "linear") and p.k >= self.fp8_min_k and p.n >= self.fp8_min_n
+
+    def _gemm_mx(self, p, a, w):
+        kc = p.cin if p.gather != GATHER_LINEAR else p.k
+        rows = p.frames * p.h_in * p.w_in if p.gather == GATHER_CONV3x3 else p.m
+        aq, asc = self.quant_mxfp8(a[:rows], kc)
+        wq, wsc = self._weight_mx(w)
+        px = TcGemmMxParams()
+        px.g = p
+        px.g.a, px.g.lda = aq.data_ptr(), aq.stride(0)
+        px.g.w, px.g.ldw = wq.data_ptr(), wq.stride(0)
+        px.a_scale, px.lda_s = asc.data_ptr(), asc.stride(0)
+        px.w_scale, px.ldw_s = wsc.data_ptr(), wsc.stride(0)
+        _lib.check(self.lib.tc_gemm_mxfp8(C.byref(px), _stream()), "tc_gemm_mxfp8")
 
     # ------------------------------------------------------------------ attention
     def attention(self, q, k, v, *, batch, heads, lq, lk, kv_bdiv=1, out=None, accumulate=False, scale=None,
