@@ -19,6 +19,8 @@ for s in "$@"; do
     fp8)     timeout 900 python -m pytest tests/test_gpu_fp8.py tests/test_gpu_fullsize.py -m gpu -q -s -p no:cacheprovider -k "fp8 or mx or quantiser or ineligible" > $OUT/fp8_tests.log 2>&1 ;;
     benchfp8) timeout 900 python bench.py --fp8 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/bench_fp8.log 2>&1
               timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/bench_bf16_same_box.log 2>&1 ;;
+    proffp8) (cd /tmp && TC_FP8=1 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/proffp8 -o prof -- python $OLDPWD/bench.py --fp8 --no-retry --steps 1 --warmup 0 --ddim-steps 6 --no-cpu-baseline --no-roofline > $OLDPWD/$OUT/proffp8.log 2>&1; python $OLDPWD/scripts/prof_summary.py "$(find /tmp/proffp8 -name '*.db' | head -1)" 30 > $OLDPWD/$OUT/proffp8_stats.txt 2>> $OLDPWD/$OUT/proffp8.log) ;;
+    torchrun1) timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/bench_torchrun1.log 2>&1 ;;
     mxbench) timeout 300 python scripts/mx_bench.py > $OUT/mx_bench.txt 2>&1 ;;
     gemmbench) timeout 600 python scripts/gemm_bench.py > $OUT/gemm_bench.log 2>&1 ;;
     attncheck) timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_guard.py tests/test_gpu_properties.py -m gpu -q -p no:cacheprovider -k "attention" > $OUT/attn_check.log 2>&1
