@@ -30,7 +30,7 @@ def test_struct_layout_matches_header():
     with open(os.path.join(ROOT, "include", "tooncrafter_hip.h")) as f:
         header = f.read()
     for cname, ctype in (("TcGemmParams", _lib.TcGemmParams), ("TcAttnParams", _lib.TcAttnParams),
-                         ("TcDdimParams", _lib.TcDdimParams)):
+                         ("TcDdimParams", _lib.TcDdimParams), ("TcGemmMxParams", _lib.TcGemmMxParams)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), header, re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []
@@ -52,3 +52,30 @@ def test_ops_refuse_cpu_tensors():
     hip = HipOps()
     with pytest.raises((TooncrafterHipError, ValueError)):
         hip.gemm(torch.zeros(8, 8, dtype=torch.bfloat16), torch.zeros(8, 8, dtype=torch.bfloat16))
+
+
+def test_fp8_routing_rule(monkeypatch):
+    """TC_FP8 routing (BASELINE configs[4]): which GEMM launches take the MXFP8 kernel -- host logic only."""
+    from tooncrafter_amd._lib import GATHER_CONV3x3, GATHER_LINEAR, TcGemmParams
+    from tooncrafter_amd.ops import HipOps
+    assert HipOps().fp8 is None                              # off unless asked for
+    monkeypatch.setenv("TC_FP8", "1")
+    h = HipOps()
+    assert h.fp8 == "all"
+
+    def prm(m, n, k, gather=GATHER_LINEAR, cin=0):
+        p = TcGemmParams()
+        p.m, p.n, p.k, p.gather, p.cin = m, n, k, gather, cin
+        return p
+    assert h._fp8_eligible(prm(20480, 1920, 640), False, 1920, 1)            # level-1 qkv: wide N
+    assert not h._fp8_eligible(prm(81920, 320, 1280), False, 320, 1)         # ff2: the quantiser costs more than it saves
+    assert not h._fp8_eligible(prm(81920, 960, 320), False, 960, 1)          # short K
+    assert not h._fp8_eligible(prm(20480, 1920, 640), False, 1920, 2)        # batched
+    assert not h._fp8_eligible(prm(77, 2048, 1024), False, 2048, 1)          # a handful of rows (context projections)
+    assert not h._fp8_eligible(prm(20480, 1284, 640), False, 1284, 1)        # N tail: the scalar epilogue stays bf16
+    assert h._fp8_eligible(prm(81920, 320, 2880, GATHER_CONV3x3, 320), True, 320, 1)
+    assert not h._fp8_eligible(prm(20480, 640, 17280, GATHER_CONV3x3, 1920), True, 640, 1)   # cin > 1280
+    monkeypatch.setenv("TC_FP8", "conv")
+    h = HipOps()
+    assert not h._fp8_eligible(prm(20480, 1920, 640), False, 1920, 1)
+    assert h._fp8_eligible(prm(81920, 320, 2880, GATHER_CONV3x3, 320), True, 320, 1)

@@ -237,6 +237,8 @@ def test_guard_softmax_layout_elementwise(hip, emu):
     assert torch.equal(hip.rows_to_nchw(rg, c=8, b=2, t=3, h=2, w=2), emu.rows_to_nchw(rows, c=8, b=2, t=3, h=2, w=2))
     rf = rnd(2 * 3 * 4, 4, seed=34, dtype=torch.float32)
     assert torch.equal(hip.rows_to_nchw(rf, c=4, b=2, t=3, h=2, w=2), emu.rows_to_nchw(rf, c=4, b=2, t=3, h=2, w=2))
+    rw = rnd(1 * 2 * 3 * 5, 40, seed=38)                     # tiled transpose: 15 pixels per frame, 40 channels
+    assert torch.equal(hip.rows_to_nchw(guard(rw), c=40, b=1, t=2, h=3, w=5), emu.rows_to_nchw(rw, c=40, b=1, t=2, h=3, w=5))
     a, b = rnd(3, 64, seed=35), rnd(3, 128, seed=36)
     assert torch.equal(hip.concat_rows(a, b), torch.cat([a, b], 1))
     t = guard(torch.tensor([999.0, 19.0, 0.0, 10.0]))

@@ -247,6 +247,14 @@ def test_layout_roundtrip(hip, emu):
     assert torch.equal(hip.concat_rows(a, b), torch.cat([a, b], 1))
 
 
+@pytest.mark.parametrize("b,t,h,w,c,ld", [(1, 2, 5, 9, 128, 128), (2, 1, 8, 8, 96, 96), (1, 3, 7, 11, 40, 64), (1, 1, 16, 20, 512, 512)])
+def test_rows_to_nchw_wide_rows_tiled(hip, emu, b, t, h, w, c, ld):
+    """bf16 rows of >= 32 channels take the LDS-tiled transpose: ragged pixel / channel tiles, column-sliced source."""
+    wide = rnd(b * t * h * w, ld, seed=40)
+    rows = wide[:, :c]
+    assert torch.equal(hip.rows_to_nchw(rows, c=c, b=b, t=t, h=h, w=w), emu.rows_to_nchw(rows, c=c, b=b, t=t, h=h, w=w))
+
+
 def test_embedding_helpers(hip, emu):
     t = torch.tensor([999.0, 19.0, 0.0, 10.0], device=DEV)
     check(hip.timestep_embedding(t, 320, 320), emu.timestep_embedding(t, 320, 320), "timestep_embedding")

@@ -52,6 +52,34 @@ __global__ void rows_to_nchw_kernel(const void* __restrict__ src, int ld, float*
   }
 }
 
+// The same conversion for wide bf16 rows (the first-stage encoder's 128..512-channel hidden states): the
+// per-element kernel above reads one 2-byte value per lane at a row stride -- 64 cache lines per wave load.  Here
+// a block moves a 64-pixel x 64-channel tile through LDS: 16-byte row-vector reads, 256-byte plane writes.
+__global__ __launch_bounds__(256) void rows_to_nchw_tiled_kernel(const bf16_t* __restrict__ src, int ld, float* __restrict__ out,
+                                                                 int c, int t, int hw) {
+  __shared__ float tile[64][65];                       // [channel][pixel], padded: both phases conflict-free
+  const int tid = threadIdx.x;
+  const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int bt = blockIdx.z, b = bt / t, tt = bt - b * t;
+  const bf16_t* rows = src + ((int64_t)bt * hw + p0) * ld + c0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pix = (tid >> 3) + 32 * i, v = tid & 7;
+    float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p0 + pix < hw && c0 + v * 8 < c) unpack8(*reinterpret_cast<const u32x4*>(rows + (int64_t)pix * ld + v * 8), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) tile[v * 8 + e][pix] = f[e];
+  }
+  __syncthreads();
+  const int pix = tid & 63;
+  if (p0 + pix >= hw) return;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int ch = (tid >> 6) + 4 * i;
+    if (c0 + ch < c) out[(((int64_t)b * c + c0 + ch) * t + tt) * hw + p0 + pix] = tile[ch][pix];
+  }
+}
+
 __global__ void concat_rows_kernel(const bf16_t* __restrict__ a, int ca, const bf16_t* __restrict__ b, int cb,
                                    bf16_t* __restrict__ out, int64_t rows) {
   const int va = ca >> 3, vb = cb >> 3, vt = va + vb;
@@ -239,6 +267,9 @@ extern "C" int tc_rows_to_nchw(const void* src, int32_t src_f32, int32_t ld, flo
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (src_f32)
     hipLaunchKernelGGL(rows_to_nchw_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, s, src, ld, out, c, b, t, hw);
+  else if (c >= 32 && (c & 7) == 0 && (ld & 7) == 0 && tc_aligned16(src) && (int64_t)b * t <= 65535 && (c + 63) / 64 <= 65535)
+    hipLaunchKernelGGL(rows_to_nchw_tiled_kernel, dim3((hw + 63) / 64, (c + 63) / 64, b * t), dim3(256), 0, s,
+                       reinterpret_cast<const bf16_t*>(src), ld, out, c, t, hw);
   else
     hipLaunchKernelGGL(rows_to_nchw_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, s, src, ld, out, c, b, t, hw);
   TC_LAUNCH_CHECK();
