@@ -124,6 +124,10 @@ class Encoder(PackedModule):
         """x: (N, 3, H, W) fp32 -> (moments rows fp32 [N*h*w, 2z], hidden Acts (4 levels + conv_in), h, w).
         `out_w/out_b`: packed replacement for conv_out (the autoencoder passes conv_out fused with its
         1x1 quant_conv)."""
+        with ops.fp8_scope("decoder"):         # the first stage (pixels <-> latents) stays bf16 under TC_FP8
+            return self._encode_rows(x, out_w, out_b)
+
+    def _encode_rows(self, x, out_w, out_b):
         n, c, hh, ww = x.shape
         pk = self.pk
         cpad = ceil_to(c, 64)

@@ -319,6 +319,10 @@ class VideoDecoder(PackedModule):
         The ~1000 launches of one decode are captured in a hipGraph per (latent shape, scale) right after the
         first (eager) decode of that geometry and replayed afterwards (static input/output buffers; the
         reference rows and K/V are refreshed in place per clip): one host call per decode instead of ~1000."""
+        with ops.fp8_scope("decoder"):         # TC_FP8 routing stops at the decoder unless TC_FP8_DECODER=1
+            return self._decode_clip(z, ref_context, scale, probe)
+
+    def _decode_clip(self, z, ref_context, scale, probe):
         ref = self.ref_cache(ref_context) if ref_context else None
         if not (self.use_hipgraph and z.is_cuda and probe is None and ops.backend().name == "hip"):
             return self._decode(z, ref, scale, probe)

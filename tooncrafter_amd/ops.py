@@ -15,6 +15,7 @@ contract (tests/emu_ops.py) to exercise the host logic without a GPU.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from typing import Optional
 
@@ -76,6 +77,7 @@ class HipOps:
         self.fp8_min_n = int(os.environ.get("TC_FP8_MIN_N", "1280"))
         self.fp8_max_cin = int(os.environ.get("TC_FP8_MAX_CIN", "1280"))
         self.fp8_min_m = 1024
+        self.fp8_decoder = os.environ.get("TC_FP8_DECODER", "0") == "1"
         self.fp8_calls = {"mx": 0, "bf16": 0}
         self._wq = {}
 
@@ -181,6 +183,19 @@ class HipOps:
         _lib.check(self.lib.tc_quant_mxfp8(x.data_ptr(), rows, k, x.stride(0), q.data_ptr(), q.stride(0),
                                            sc.data_ptr(), lds, _stream()), "tc_quant_mxfp8")
         return q, sc
+
+    @contextlib.contextmanager
+    def fp8_scope(self, name):
+        """Modules whose output precision matters more than their time opt out of the fp8 routing: the VAE decoder
+        writes the pixels (measured at full size: 1.3e-1 from the fp32 oracle with MXFP8 convolutions against 1.3e-2
+        in bf16, for 3 ms per decode) -- TC_FP8_DECODER=1 opts it back in."""
+        old = self.fp8
+        if name == "decoder" and not self.fp8_decoder:
+            self.fp8 = None
+        try:
+            yield
+        finally:
+            self.fp8 = old
 
     def _weight_mx(self, w):
         """Quantised copy of a packed weight matrix, made once per weight tensor (held while the tensor lives)."""
@@ -429,6 +444,17 @@ def backend():
         else:
             _backend = HipOps()   # raises if libtooncrafter_hip.so is missing: no fallback
     return _backend
+
+
+@contextlib.contextmanager
+def fp8_scope(name):
+    """`with ops.fp8_scope("decoder"):` -- see HipOps.fp8_scope; a no-op for backends without an fp8 path."""
+    fn = getattr(backend(), "fp8_scope", None)
+    if fn is None:
+        yield
+    else:
+        with fn(name):
+            yield
 
 
 def set_backend(b):
