@@ -60,6 +60,8 @@ def test_fp8_routing_rule(monkeypatch):
     from tooncrafter_amd.ops import HipOps
     assert HipOps().fp8 is None                              # off unless asked for
     monkeypatch.setenv("TC_FP8", "1")
+    assert HipOps().fp8 == "linear"                          # the default fp8 mode: wide-N projections only
+    monkeypatch.setenv("TC_FP8", "all")
     h = HipOps()
     assert h.fp8 == "all"
 

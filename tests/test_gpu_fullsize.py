@@ -161,23 +161,27 @@ def test_decoder_full_size_vs_oracle(full_model, golden, inp, tag):
     assert all(e_st[n] <= 1.5 * DEC_STAGE_FLOOR[n] for n in fc.PROBES), e_st
 
 
-# MXFP8 GEMM path (BASELINE.json configs[4]): its OWN parity bound.  The kernels are exact against the MX
+# MXFP8 GEMM path (BASELINE.json configs[4]): its OWN parity bounds.  The kernels are exact against the MX
 # restatement (tests/test_gpu_fp8.py); what is bounded here is the error the 8-bit operand format introduces into
-# one full-size UNet forward, against the same fp32 CPU oracle golden.  Measured: see the table in DESIGN.md 6.
-UNET_FP8_REL, UNET_FP8_COS = 1.8e-1, 0.985      # measured 1.41e-1 / 0.9901 (bf16 path: 1.44e-2)
+# one full-size UNet forward, against the same fp32 CPU oracle golden (profiles/r02_fp8_error_by_layer_class.txt):
+#   TC_FP8=1 ("linear": wide-N projections, 109 launches)   2.86e-2  -> bound 3.6e-2 (2.1 x the bf16-autocast floor)
+#   TC_FP8=all (+ 3x3 / temporal convolutions, 201 launches)  1.41e-1  -> bound 1.8e-1
+UNET_FP8 = {"linear": (3.6e-2, 0.9990, 100), "all": (1.8e-1, 0.985, 190)}
 
 
 @pytest.mark.timeout(1500)
-def test_unet_full_size_fp8(full_model, golden, inp):
+@pytest.mark.parametrize("mode", ["linear", "all"])
+def test_unet_full_size_fp8(full_model, golden, inp, mode):
     be = ops.backend()
     un = full_model.model.diffusion_model
     ts = torch.tensor([fc.UNET_T], device=DEV)
     args = dict(context=inp["cond"].to(DEV), fs=inp["fs"].to(DEV))
     parts = [inp["x_T"].to(DEV), inp["c_concat"].to(DEV)]
+    bound, cos_min, min_calls = UNET_FP8[mode]
     with torch.no_grad():
         y16 = un(None, ts, x_parts=parts, **args).cpu()
         old, c0 = be.fp8, dict(be.fp8_calls)
-        be.fp8 = "all"
+        be.fp8 = mode
         try:
             y8 = un(None, ts, x_parts=parts, **args).cpu()
         finally:
@@ -185,10 +189,10 @@ def test_unet_full_size_fp8(full_model, golden, inp):
     calls = {k: be.fp8_calls[k] - c0[k] for k in c0}
     ref = torch.from_numpy(golden["unet_y"])
     e8, c8, e16 = rel_l2(y8, ref), cosine(y8, ref), rel_l2(y16, ref)
-    print(f"full-size UNet, MXFP8 on {calls['mx']} of {calls['mx'] + calls['bf16']} GEMM launches: rel-L2 vs fp32 oracle "
-          f"{e8:.3e} (bf16 path {e16:.3e}), cosine {c8:.6f}; fp8 vs bf16 path {rel_l2(y8, y16):.3e}")
-    assert calls["mx"] > 100 and torch.isfinite(y8).all()
-    assert e8 <= UNET_FP8_REL and c8 >= UNET_FP8_COS
+    print(f"full-size UNet, TC_FP8={mode}: MXFP8 on {calls['mx']} of {calls['mx'] + calls['bf16']} GEMM launches: rel-L2 vs fp32 "
+          f"oracle {e8:.3e} (bf16 path {e16:.3e}), cosine {c8:.6f}; fp8 vs bf16 path {rel_l2(y8, y16):.3e}")
+    assert calls["mx"] > min_calls and torch.isfinite(y8).all()
+    assert e8 <= bound and c8 >= cos_min
 
 
 DEC_FP8_REL = 1.6e-1       # measured 1.30e-1 (bf16 path: 1.30e-2): why TC_FP8 leaves the decoder in bf16 by default

@@ -69,13 +69,17 @@ class HipOps:
         import os
         self.lib = _lib.load()
         self._ws = {}
-        # BASELINE.json configs[4]: TC_FP8=1 routes the eligible GEMMs (see _fp8_eligible) through MXFP8 operands --
-        # weights quantised once, activations by tc_quant_mxfp8 in front of each GEMM.  TC_FP8=conv|linear narrows it.
+        # BASELINE.json configs[4]: TC_FP8 routes eligible GEMMs (see _fp8_eligible) through MXFP8 operands -- weights
+        # quantised once, activations by tc_quant_mxfp8 in front of each GEMM.  TC_FP8=1 = "linear": the wide-N
+        # projections (qkv, GEGLU), which carry most of the time gain at 2x the bf16 error of a UNet forward;
+        # "all" adds the 3x3 / temporal convolutions (10x the bf16 error, profiles/r02_fp8_error_by_layer_class.txt);
+        # "conv" | "conv3" | "convt" select those alone.
         mode = os.environ.get("TC_FP8", "0").lower()
-        self.fp8 = None if mode in ("0", "", "off") else ("all" if mode in ("1", "on", "all") else mode)
+        self.fp8 = None if mode in ("0", "", "off") else ("linear" if mode in ("1", "on") else mode)
         self.fp8_min_k = int(os.environ.get("TC_FP8_MIN_K", "640"))
         self.fp8_min_n = int(os.environ.get("TC_FP8_MIN_N", "1280"))
         self.fp8_max_cin = int(os.environ.get("TC_FP8_MAX_CIN", "1280"))
+        self.fp8_min_cin = int(os.environ.get("TC_FP8_MIN_CIN", "0"))
         self.fp8_min_m = 1024
         self.fp8_decoder = os.environ.get("TC_FP8_DECODER", "0") == "1"
         self.fp8_calls = {"mx": 0, "bf16": 0}
@@ -216,7 +220,8 @@ class HipOps:
         # temporal convolutions up to cin = 1280 (one quantisation feeds 9 / 3 taps) and on linear layers whose N is
         # large against K (qkv, GEGLU); short-K or narrow-N linear layers lose to the extra pass and stay bf16
         if is_conv:
-            return self.fp8 in ("all", "conv") and p.cin % 64 == 0 and p.cin <= self.fp8_max_cin
+            kind = "conv3" if p.gather == GATHER_CONV3x3 else "convt"
+            return self.fp8 in ("all", "conv", kind) and p.cin % 64 == 0 and self.fp8_min_cin <= p.cin <= self.fp8_max_cin
         return self.fp8 in ("all", "linear") and p.k >= self.fp8_min_k and p.n >= self.fp8_min_n
 
     def _gemm_mx(self, p, a, w):
