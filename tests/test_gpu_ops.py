@@ -310,6 +310,20 @@ def test_gemm_split_k_low_resolution_layers(hip, emu):
     assert hip.lib.tc_gemm_workspace(C.byref(p)) == 0                         # short K: 64x64 tiles instead
 
 
+@pytest.mark.parametrize("m,n,k", [(1280, 1280, 1280), (1000, 264, 704), (130, 3840, 1280), (2048, 200, 320), (77, 64, 64)])
+def test_gemm_w_stationary_walk_is_the_same_gemm(hip, emu, monkeypatch, m, n, k):
+    """TC_GEMM_NMAJOR=2 forces the W-stationary tile walk (N-major tiles dealt to the XCDs in 8 contiguous runs,
+    surplus blocks exit): ragged tile counts, tile counts below 8, and the default walk must agree bit for bit."""
+    a, w = rnd(m, k, seed=90), rnd(n, k, seed=91, scale=k ** -0.5)
+    bias, res = rnd(n, seed=92, dtype=torch.float32), rnd(m, n, seed=93)
+    monkeypatch.setenv("TC_GEMM_NMAJOR", "0")
+    base = hip.gemm(a, w, bias, residual=res)
+    monkeypatch.setenv("TC_GEMM_NMAJOR", "2")
+    walk = hip.gemm(a, w, bias, residual=res)
+    assert torch.equal(base, walk)
+    check(walk, emu.gemm(a, w, bias, residual=res), f"W-stationary walk {m}x{n}x{k}")
+
+
 def test_gemm_chunked_tile_order_for_wide_n(hip, emu):
     """Layers whose weight matrix outgrows one XCD's L2 (N*K*2 > 4 MiB, >= 16 N-tiles) walk their tiles in
     chunks of 8 N-tiles x all M-tiles of the XCD: a different, still bijective block -> tile map.  Ragged M,

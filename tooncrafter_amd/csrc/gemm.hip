@@ -353,10 +353,11 @@ extern "C" int tc_gemm_bf16(const TcGemmParams* pp, void* stream) {
   const int bm = 64 * tm, bn = 64 * tn;
   const int tiles_n = (p.n + bn - 1) / bn;
   const int tiles_m = (p.m + bm - 1) / bm;
-  const int64_t nblk = (int64_t)tiles_n * 8 * ((tiles_m + 7) / 8);
+  const bool nmajor = tc_gemm_nmajor(p);
+  const int64_t nblk = nmajor ? 8 * (((int64_t)tiles_m * tiles_n + 7) / 8) : (int64_t)tiles_n * 8 * ((tiles_m + 7) / 8);
   if (nblk > 0x7fffffffLL || batch > 65535) return TC_ESHAPE;
   dim3 grid((unsigned)nblk, (unsigned)splits, (unsigned)batch), block(256);
-  const int order = tc_gemm_tile_order(p, tiles_n);
+  const int order = nmajor ? -1 : tc_gemm_tile_order(p, tiles_n);
 #define TC_LAUNCH_GEMM(G)                                                                           \
   do {                                                                                              \
     if (tm == 2 && tn == 2) hipLaunchKernelGGL((gemm_kernel<G, 2, 2>), grid, block, 0, s, p, splits, order);      \

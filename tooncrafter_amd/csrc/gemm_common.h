@@ -78,6 +78,18 @@ __device__ __forceinline__ void glds16(tc_rsrc_t rsrc, char* lds, uint32_t voff,
 __device__ __forceinline__ void tc_tile_of_block(int bid, int tiles_m, int tiles_n, int order, int& tile_m, int& tile_n) {
   const int xcd = bid & 7;
   const int slot = bid >> 3;
+  if (order < 0) {
+    // W-stationary walk for the low-resolution layers (few rows, big weight matrices): tiles in N-major order, cut
+    // into 8 contiguous runs, one per XCD -- an XCD touches ~tiles_n / 8 + 1 N-tiles of W instead of all of them
+    // (order 0 makes every L2 fetch the whole weight matrix and, with tiles_m = 10, gives two XCDs twice the work)
+    const int total = tiles_m * tiles_n;
+    const int per = (total + 7) >> 3;
+    const int lin = xcd * per + slot;
+    if (slot >= per || lin >= total) { tile_m = tiles_m; tile_n = 0; return; }   // surplus block: caller exits
+    tile_n = lin / tiles_m;
+    tile_m = lin - tile_n * tiles_m;
+    return;
+  }
   if (order == 0) {
     tile_m = (slot / tiles_n) * 8 + xcd;
     tile_n = slot % tiles_n;
@@ -197,6 +209,19 @@ inline bool tc_gemm_offsets_fit(const TcGemmParams& p) {
   const int64_t a_bytes = tc_a_rows(p) * p.lda * 2;
   const int64_t w_bytes = (int64_t)p.n * p.ldw * 2;
   return a_bytes < 0x7fffff00LL && w_bytes < 0x7fffff00LL;
+}
+
+// host side: -1 (W-stationary walk) for the lowest-resolution layers (M <= 2048 rows) whose weight matrix outweighs
+// their activation rows.  Measured (profiles/r02_nmajor_ab.txt): +5-7 % on the level-3 convolutions and qkv, neutral
+// on the rest of level 3, 3-7 % SLOWER on the level-2 convolutions (40 M-tiles: the A halo re-reads cost more than
+// the W re-reads the Infinity Cache was already absorbing) -- hence the row limit.
+// TC_GEMM_NMAJOR = 0 never, 1 heuristic (default), 2 always; read per call.
+inline bool tc_gemm_nmajor(const TcGemmParams& p) {
+  const char* e = getenv("TC_GEMM_NMAJOR");
+  const int mode = e ? atoi(e) : 1;
+  if (mode == 0 || (p.batch > 1)) return false;
+  if (mode == 2) return true;
+  return p.m <= 2048 && tc_w_extent(p) > tc_a_extent(p);
 }
 
 int tc_gemm_wide_try(const TcGemmParams& p, int batch, hipStream_t s, bool force);   // gemm_wide.hip; 1 = launched
