@@ -56,6 +56,17 @@ def test_torch_ops_match_ctypes_binding_bitwise(both):
     sc = dict(cfg_scale=7.5, guidance_rescale=0.7, sqrt_ac=0.6, sqrt_1m_ac=0.8, sqrt_a_prev=0.7, dir_coef=0.5, sigma=0.3, x0_rescale=0.98)
     for u, v in zip(t.ddim_step(*lat, **sc), c.ddim_step(*lat, **sc)):
         assert torch.equal(u, v)
+    # MXFP8 pair through the op layer: same bytes as the ctypes binding, same GEMM result as HipOps' fp8 route
+    aq_t, as_t = t.quant_mxfp8(a, 320)
+    aq_c, as_c = c.quant_mxfp8(a, 320)
+    assert torch.equal(aq_t, aq_c) and torch.equal(as_t, as_c)
+    wq, ws = t.quant_mxfp8(w, 320)
+    y_t = t.t.gemm_mx(aq_t, as_t, wq, ws, b, res, None, 0, ACT_NONE, 1.0, 1.0, False, [])
+    c.fp8, c.fp8_min_k, c.fp8_min_n, c.fp8_min_m = "linear", 0, 0, 1
+    try:
+        assert torch.equal(y_t, c.gemm(a, w, b, residual=res))
+    finally:
+        c.fp8 = None
     with pytest.raises(RuntimeError):
         t.gemm(a[:, :60], w[:, :60].contiguous())                  # K not a multiple of 8: the C ABI's TC_EALIGN surfaces
 

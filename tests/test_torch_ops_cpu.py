@@ -15,7 +15,7 @@ def t():
 
 def test_operator_namespace_and_abi(t):
     assert int(t.abi_version()) == _lib.TC_ABI_VERSION
-    for name in ("gemm", "attention", "attention_temporal", "groupnorm", "layernorm", "ddim_step"):
+    for name in ("gemm", "quant_mxfp8", "gemm_mx", "attention", "attention_temporal", "groupnorm", "layernorm", "ddim_step"):
         op = getattr(t, name)
         schema = str(op.default._schema)
         assert schema.startswith(f"tooncrafter::{name}("), schema
@@ -34,6 +34,10 @@ def test_meta_kernels_infer_shapes(t):
     conv = [1, 320, 32, 1, 40, 64, 20, 32, 2, 0, 1]
     y = t.gemm(a, wc, None, None, None, 0, 0, 1.0, 1.0, True, conv)
     assert y.shape == (32 * 20 * 32, 320) and y.dtype == torch.float32
+    aq, asc = t.quant_mxfp8(a, 320)                                              # MXFP8 pair: bytes + one scale per 32 K
+    assert aq.shape == (81920, 320) and asc.shape == (81920, 12) and aq.dtype == asc.dtype == torch.uint8
+    wq, wsc = t.quant_mxfp8(w, 320)
+    assert t.gemm_mx(aq, asc, wq, wsc, None, None, None, 0, 0, 1.0, 1.0, False, []).shape == (81920, 960)
     q, kv = torch.empty(32 * 2560, 320, **bf), torch.empty(2 * 77, 320, **bf)
     ki = torch.empty(32 * 16, 320, **bf)
     assert t.attention(q, kv, kv, 32, 5, 2560, 77, 16, 0.125, ki, ki, 16, 1).shape == (32 * 2560, 320)

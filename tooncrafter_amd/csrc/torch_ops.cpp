@@ -2,7 +2,7 @@
 //
 // The reference binds ATen / xformers operators from Python (utils/utils.py:27-42 instantiates lvdm classes whose
 // forward methods call torch ops); this registers the MI355X kernels as first-class torch operators instead:
-//   torch.ops.tooncrafter.gemm / attention / attention_temporal / groupnorm / layernorm / ddim_step
+//   torch.ops.tooncrafter.gemm / quant_mxfp8 / gemm_mx / attention / attention_temporal / groupnorm / layernorm / ddim_step
 // with (i) a CUDA(HIP)-key implementation that validates the tensors, allocates the result from the caching allocator,
 // picks up the CURRENT stream and calls the same extern "C" entry point the ctypes binding calls, and (ii) a Meta-key
 // implementation (shape / dtype inference only) so the ops can be traced, exported and shape-checked without a GPU.
@@ -50,18 +50,14 @@ GemmGeom gemm_geom(const Tensor& a, const Tensor& w, int64_t act, at::IntArrayRe
   return g;
 }
 
-Tensor gemm_cuda(const Tensor& a, const Tensor& w, const optional<Tensor>& bias, const optional<Tensor>& residual,
-                 const optional<Tensor>& row_bias, int64_t row_div, int64_t act, double alpha, double out_scale,
-                 bool out_f32, at::IntArrayRef conv) {
-  check_rows(a, "gemm: a");
-  check_rows(w, "gemm: w");
+// fills everything of TcGemmParams except a / w / lda / ldw (operand dtype differs between the bf16 and MXFP8 ops)
+void fill_gemm(TcGemmParams& p, const Tensor& a, const GemmGeom& g, Tensor& out, const optional<Tensor>& bias,
+               const optional<Tensor>& residual, const optional<Tensor>& row_bias, int64_t row_div, int64_t act, double alpha,
+               double out_scale, bool out_f32, at::IntArrayRef conv) {
   TORCH_CHECK(conv.empty() || conv.size() == 11, "gemm: conv must be empty or 11 integers");
-  const GemmGeom g = gemm_geom(a, w, act, conv);
-  Tensor out = at::empty({g.m, g.n_out}, a.options().dtype(out_f32 ? at::kFloat : at::kBFloat16));
-  TcGemmParams p = {};
-  p.a = bf(a); p.w = bf(w); p.c = out.data_ptr();
+  p.c = out.data_ptr();
   p.m = (int32_t)g.m; p.n = (int32_t)g.n; p.k = (int32_t)g.k;
-  p.lda = (int32_t)a.stride(0); p.ldw = (int32_t)w.stride(0); p.ldc = (int32_t)out.stride(0);
+  p.ldc = (int32_t)out.stride(0);
   p.alpha = (float)alpha; p.out_scale = (float)out_scale; p.act = (int32_t)act; p.out_f32 = out_f32 ? 1 : 0;
   p.batch = 1;
   if (bias.has_value()) {
@@ -89,6 +85,19 @@ Tensor gemm_cuda(const Tensor& a, const Tensor& w, const optional<Tensor>& bias,
     p.stride = (int32_t)conv[8]; p.upsample = (int32_t)conv[9]; p.pad = (int32_t)conv[10];
     TORCH_CHECK(a.size(0) >= (int64_t)p.frames * p.h_in * p.w_in && a.size(1) >= p.cin, "gemm: conv source too small for its geometry");
   }
+}
+
+Tensor gemm_cuda(const Tensor& a, const Tensor& w, const optional<Tensor>& bias, const optional<Tensor>& residual,
+                 const optional<Tensor>& row_bias, int64_t row_div, int64_t act, double alpha, double out_scale,
+                 bool out_f32, at::IntArrayRef conv) {
+  check_rows(a, "gemm: a");
+  check_rows(w, "gemm: w");
+  const GemmGeom g = gemm_geom(a, w, act, conv);
+  Tensor out = at::empty({g.m, g.n_out}, a.options().dtype(out_f32 ? at::kFloat : at::kBFloat16));
+  TcGemmParams p = {};
+  p.a = bf(a); p.w = bf(w);
+  p.lda = (int32_t)a.stride(0); p.ldw = (int32_t)w.stride(0);
+  fill_gemm(p, a, g, out, bias, residual, row_bias, row_div, act, alpha, out_scale, out_f32, conv);
   Tensor ws;
   const int64_t nbytes = tc_gemm_workspace(&p);
   if (nbytes > 0) {
@@ -97,6 +106,47 @@ Tensor gemm_cuda(const Tensor& a, const Tensor& w, const optional<Tensor>& bias,
   }
   check_rc(tc_gemm_bf16(&p, cur_stream()), "tc_gemm_bf16");
   return out;
+}
+
+// MXFP8 pair (ABI 7, BASELINE.json configs[4]): bf16 rows -> (e4m3 bytes, E8M0 scales); GEMM over such operands
+std::tuple<Tensor, Tensor> quant_mxfp8_cuda(const Tensor& x, int64_t k) {
+  check_rows(x, "quant_mxfp8: x");
+  TORCH_CHECK(k > 0 && k % 32 == 0 && x.size(1) >= k, "quant_mxfp8: k must be a multiple of 32 and <= the columns of x");
+  const int64_t rows = x.size(0), lds = (k + 127) / 128 * 4;
+  Tensor q = at::empty({rows, k}, x.options().dtype(at::kByte));
+  Tensor s = at::empty({rows, lds}, x.options().dtype(at::kByte));
+  check_rc(tc_quant_mxfp8(bf(x), rows, (int32_t)k, (int32_t)x.stride(0), q.data_ptr<uint8_t>(), (int32_t)q.stride(0),
+                          s.data_ptr<uint8_t>(), (int32_t)lds, cur_stream()), "tc_quant_mxfp8");
+  return {q, s};
+}
+
+std::tuple<Tensor, Tensor> quant_mxfp8_meta(const Tensor& x, int64_t k) {
+  return {at::empty({x.size(0), k}, x.options().dtype(at::kByte)),
+          at::empty({x.size(0), (k + 127) / 128 * 4}, x.options().dtype(at::kByte))};
+}
+
+Tensor gemm_mx_cuda(const Tensor& aq, const Tensor& a_scale, const Tensor& wq, const Tensor& w_scale, const optional<Tensor>& bias,
+                    const optional<Tensor>& residual, const optional<Tensor>& row_bias, int64_t row_div, int64_t act,
+                    double alpha, double out_scale, bool out_f32, at::IntArrayRef conv) {
+  check_rows(aq, "gemm_mx: a", at::kByte); check_rows(wq, "gemm_mx: w", at::kByte);
+  check_rows(a_scale, "gemm_mx: a_scale", at::kByte); check_rows(w_scale, "gemm_mx: w_scale", at::kByte);
+  TORCH_CHECK(a_scale.size(0) == aq.size(0) && w_scale.size(0) == wq.size(0), "gemm_mx: one scale row per operand row");
+  const GemmGeom g = gemm_geom(aq, wq, act, conv);
+  Tensor out = at::empty({g.m, g.n_out}, aq.options().dtype(out_f32 ? at::kFloat : at::kBFloat16));
+  TcGemmMxParams px = {};
+  px.g.a = reinterpret_cast<const tc_bf16*>(aq.data_ptr()); px.g.w = reinterpret_cast<const tc_bf16*>(wq.data_ptr());
+  px.g.lda = (int32_t)aq.stride(0); px.g.ldw = (int32_t)wq.stride(0);
+  fill_gemm(px.g, aq, g, out, bias, residual, row_bias, row_div, act, alpha, out_scale, out_f32, conv);
+  px.a_scale = a_scale.data_ptr<uint8_t>(); px.lda_s = (int32_t)a_scale.stride(0);
+  px.w_scale = w_scale.data_ptr<uint8_t>(); px.ldw_s = (int32_t)w_scale.stride(0);
+  check_rc(tc_gemm_mxfp8(&px, cur_stream()), "tc_gemm_mxfp8");
+  return out;
+}
+
+Tensor gemm_mx_meta(const Tensor& aq, const Tensor&, const Tensor& wq, const Tensor&, const optional<Tensor>&, const optional<Tensor>&,
+                    const optional<Tensor>&, int64_t, int64_t act, double, double, bool out_f32, at::IntArrayRef conv) {
+  const GemmGeom g = gemm_geom(aq, wq, act, conv);
+  return at::empty({g.m, g.n_out}, aq.options().dtype(out_f32 ? at::kFloat : at::kBFloat16));
 }
 
 Tensor gemm_meta(const Tensor& a, const Tensor& w, const optional<Tensor>&, const optional<Tensor>&, const optional<Tensor>&,
@@ -219,6 +269,9 @@ std::tuple<Tensor, Tensor> ddim_step_meta(const Tensor& x, const Tensor&, const 
 TORCH_LIBRARY(tooncrafter, m) {
   m.def("gemm(Tensor a, Tensor w, Tensor? bias, Tensor? residual, Tensor? row_bias, int row_div, int act, float alpha, "
         "float out_scale, bool out_f32, int[] conv) -> Tensor");
+  m.def("quant_mxfp8(Tensor x, int k) -> (Tensor, Tensor)");
+  m.def("gemm_mx(Tensor aq, Tensor a_scale, Tensor wq, Tensor w_scale, Tensor? bias, Tensor? residual, Tensor? row_bias, "
+        "int row_div, int act, float alpha, float out_scale, bool out_f32, int[] conv) -> Tensor");
   m.def("attention(Tensor q, Tensor k, Tensor v, int batch, int heads, int lq, int lk, int kv_bdiv, float scale, "
         "Tensor? k2, Tensor? v2, int lk2, int kv2_bdiv) -> Tensor");
   m.def("attention_temporal(Tensor qkv, int b, int t, int hw, int heads, float scale) -> Tensor");
@@ -232,6 +285,8 @@ TORCH_LIBRARY(tooncrafter, m) {
 
 TORCH_LIBRARY_IMPL(tooncrafter, CUDA, m) {
   m.impl("gemm", gemm_cuda);
+  m.impl("quant_mxfp8", quant_mxfp8_cuda);
+  m.impl("gemm_mx", gemm_mx_cuda);
   m.impl("attention", attention_cuda);
   m.impl("attention_temporal", attention_temporal_cuda);
   m.impl("groupnorm", groupnorm_cuda);
@@ -241,6 +296,8 @@ TORCH_LIBRARY_IMPL(tooncrafter, CUDA, m) {
 
 TORCH_LIBRARY_IMPL(tooncrafter, Meta, m) {
   m.impl("gemm", gemm_meta);
+  m.impl("quant_mxfp8", quant_mxfp8_meta);
+  m.impl("gemm_mx", gemm_mx_meta);
   m.impl("attention", attention_meta);
   m.impl("attention_temporal", attention_temporal_meta);
   m.impl("groupnorm", like_meta3);
