@@ -118,6 +118,11 @@ int tc_gemm_mxfp8(const TcGemmMxParams* p, void* stream);
  * scale columns [k / 32, lds) are zero-filled so a K tail of the GEMM reads finite scales. */
 int tc_quant_mxfp8(const tc_bf16* x, int64_t rows, int32_t k, int32_t ld, uint8_t* q, int32_t ldq,
                    uint8_t* s, int32_t lds, void* stream);
+/* tc_layernorm followed by tc_quant_mxfp8 in one pass (the quantiser fused into its producer): nn.LayerNorm
+ * (attention.py:225-227) whose only consumer is an MXFP8 GEMM (qkv / GEGLU projections).  Bit-identical to the two
+ * separate calls.  c % 32 == 0; lds >= ceil(c / 128) * 4 as for tc_quant_mxfp8. */
+int tc_layernorm_mxfp8(const tc_bf16* x, uint8_t* q, int32_t ldq, uint8_t* s, int32_t lds, const float* gamma,
+                       const float* beta, int32_t rows, int32_t c, float eps, void* stream);
 
 typedef struct TcAttnParams {
   const tc_bf16* q; const tc_bf16* k; const tc_bf16* v; tc_bf16* o;

@@ -144,7 +144,7 @@ class EmuOps:
             y = F.silu(y)
         return self._out(y.permute(0, 2, 1).reshape(samples * rows, c)).contiguous()
 
-    def layernorm(self, x, gamma, beta, eps=1e-5):
+    def layernorm(self, x, gamma, beta, eps=1e-5, mx_for=None):
         return self._out(F.layer_norm(_f(x), (x.shape[1],), gamma, beta, eps))
 
     def softmax_rows(self, s, n=None, causal_period=0):

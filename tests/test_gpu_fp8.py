@@ -171,3 +171,34 @@ def test_ineligible_shapes_stay_on_the_bf16_kernel(hip8, emu):
     c0 = dict(hip8.fp8_calls)
     check(hip8.gemm(a, w), emu.gemm(a, w), "bf16 fallthrough")
     assert hip8.fp8_calls["bf16"] == c0["bf16"] + 1 and hip8.fp8_calls["mx"] == c0["mx"]
+
+
+@pytest.mark.parametrize("rows,c", [(1000, 320), (77, 640), (130, 1280), (33, 960), (64, 512), (5, 2048)])
+def test_layernorm_emitting_mxfp8_is_layernorm_then_quantiser(hip8, rows, c):
+    """tc_layernorm_mxfp8 (the quantiser fused into its producer) == tc_quant_mxfp8(tc_layernorm(x)), bit for bit,
+    scale padding included; and the GEMM fed with it == the GEMM fed with the bf16 rows."""
+    from tooncrafter_amd.ops import MxRows
+    x = rnd(rows, c, seed=50, scale=3.0)
+    g, b = rnd(c, seed=51, dtype=torch.float32), rnd(c, seed=52, dtype=torch.float32)
+    y = hip8.layernorm(x, g, b)
+    q_ref, s_ref = hip8.quant_mxfp8(y)
+    mx_rows = hip8.layernorm(x, g, b, mx_for=(4 * c, 4 * c))
+    assert isinstance(mx_rows, MxRows) and mx_rows.shape == (rows, c)
+    assert torch.equal(mx_rows.q, q_ref) and torch.equal(mx_rows.scales, s_ref)
+    w = rnd(4 * c, c, seed=53, scale=c ** -0.5)
+    c0 = dict(hip8.fp8_calls)
+    fused = hip8.gemm(mx_rows, w)
+    ran_mx(hip8, c0)
+    assert torch.equal(fused, hip8.gemm(y, w))
+
+
+def test_layernorm_keeps_bf16_when_its_consumer_is_not_routed(hip8):
+    x = rnd(64, 320, seed=54)
+    g, b = rnd(320, seed=55, dtype=torch.float32), rnd(320, seed=56, dtype=torch.float32)
+    old = hip8.fp8_min_n
+    hip8.fp8_min_n = 4096
+    try:
+        y = hip8.layernorm(x, g, b, mx_for=(960, 960))
+    finally:
+        hip8.fp8_min_n = old
+    assert isinstance(y, torch.Tensor) and y.dtype == BF16

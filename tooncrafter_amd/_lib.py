@@ -73,6 +73,8 @@ SYMBOLS = {
     "tc_gemm_mxfp8": (C.c_int, [C.POINTER(TcGemmMxParams), C.c_void_p]),
     "tc_quant_mxfp8": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                  C.c_void_p]),
+    "tc_layernorm_mxfp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                     C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "tc_attn_d64": (C.c_int, [C.POINTER(TcAttnParams), C.c_void_p]),
     "tc_attn_temporal": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_float, C.c_void_p]),

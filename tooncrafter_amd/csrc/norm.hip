@@ -347,10 +347,14 @@ __global__ __launch_bounds__(T) void gn_onepass_kernel(const bf16_t* __restrict_
 // two-pass variance.  R > 1 for the narrow rows (C <= 512: R = 4, C <= 1024: R = 2) puts several row loads in
 // flight per wave -- at C = 320 only 40 of the 64 lanes carry data, so one row per wave left the kernel
 // latency-bound (4.1 TB/s).
-template <int NV, int R>
+// MX = true (tc_layernorm_mxfp8): the normalised row leaves as MXFP8 -- e4m3 bytes q[row, ldq] plus one E8M0 scale per
+// 32 channels s[row, lds] -- instead of bf16: exactly tc_quant_mxfp8 applied to the bf16 result (the value is rounded
+// to bf16 first), without the bf16 round trip through HBM.  A 32-channel block is 4 adjacent lanes.
+template <int NV, int R, bool MX = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       int rows, int c, float eps) {
+                                                       int rows, int c, float eps, uint8_t* __restrict__ q = nullptr,
+                                                       int ldq = 0, uint8_t* __restrict__ sc = nullptr, int lds = 0) {
   const int lane = threadIdx.x & 63;
   const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
   if (row0 >= rows) return;
@@ -410,9 +414,36 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
             o[e] = (f[r][i][e] - mean[r]) * rstd[r] * g0[e] + b0[e];
             o[4 + e] = (f[r][i][4 + e] - mean[r]) * rstd[r] * g1[e] + b1[e];
           }
-          *reinterpret_cast<u32x4*>(y + (int64_t)(row0 + r) * c + v * 8) = pack8(o);
+          const u32x4 packed = pack8(o);
+          if (!MX) {
+            *reinterpret_cast<u32x4*>(y + (int64_t)(row0 + r) * c + v * 8) = packed;
+          } else {
+            uint32_t amax = 0;                               // |value| as bf16 bits, as in quant_mx_kernel
+#pragma unroll
+            for (int e = 0; e < 4; ++e) amax = max(amax, max(packed[e] & 0x7fffu, (packed[e] >> 16) & 0x7fffu));
+            amax = max(amax, (uint32_t)__shfl_xor((int)amax, 1, 64));
+            amax = max(amax, (uint32_t)__shfl_xor((int)amax, 2, 64));
+            const int e8 = (int)(amax >> 7);
+            const int byte = e8 - 8 < 0 ? 0 : (e8 - 8 > 254 ? 254 : e8 - 8);
+            const float inv = __uint_as_float((uint32_t)(254 - byte) << 23);
+            float t[8];
+            unpack8(packed, t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = fminf(fmaxf(t[e] * inv, -448.f), 448.f);
+            int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], 0, false);
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], w0, true);
+            int w1 = __builtin_amdgcn_cvt_pk_fp8_f32(t[4], t[5], 0, false);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(t[6], t[7], w1, true);
+            *reinterpret_cast<u32x2*>(q + (int64_t)(row0 + r) * ldq + v * 8) = u32x2{(uint32_t)w0, (uint32_t)w1};
+            if ((v & 3) == 0) sc[(int64_t)(row0 + r) * lds + (v >> 2)] = (uint8_t)byte;
+          }
         }
       }
+    } else if (MX && v - vpr < lds - (c >> 5)) {
+      // padding columns of the scale matrix (K not a multiple of 128) are written as zeros by the first idle lanes
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (row0 + r < rows) sc[(int64_t)(row0 + r) * lds + (c >> 5) + (v - vpr)] = 0;
     }
   }
 }
@@ -535,6 +566,26 @@ extern "C" int tc_layernorm(const tc_bf16* x, tc_bf16* y, const float* gamma, co
     hipLaunchKernelGGL((layernorm_kernel<2, 2>), dim3((rows + 7) / 8), dim3(256), 0, st, xb, yb, gamma, beta, rows, c, eps);
   else
     hipLaunchKernelGGL((layernorm_kernel<4, 1>), dim3((rows + 3) / 4), dim3(256), 0, st, xb, yb, gamma, beta, rows, c, eps);
+  TC_LAUNCH_CHECK();
+  return TC_OK;
+}
+
+extern "C" int tc_layernorm_mxfp8(const tc_bf16* x, uint8_t* q, int32_t ldq, uint8_t* sc, int32_t lds, const float* gamma,
+                                  const float* beta, int32_t rows, int32_t c, float eps, void* stream) {
+  if (!x || !q || !sc || !gamma || !beta || rows <= 0 || c <= 0) return TC_EINVAL;
+  if ((c % 32) != 0 || c > 4 * 64 * 8 || ldq < c || lds * 32 < c) return TC_ESHAPE;
+  if (!tc_aligned16(x) || !tc_aligned16(gamma) || !tc_aligned16(beta) || (reinterpret_cast<uintptr_t>(q) & 7u) || (ldq & 7)) return TC_EALIGN;
+  const int vpr = c >> 3, pad = lds - (c >> 5);
+  const int nv = c <= 512 ? 1 : (c <= 1024 ? 2 : 4);
+  if (vpr + pad > 64 * nv) return TC_ESHAPE;               // no idle lanes left to zero the scale padding
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const bf16_t* xb = reinterpret_cast<const bf16_t*>(x);
+  if (c <= 512)
+    hipLaunchKernelGGL((layernorm_kernel<1, 4, true>), dim3((rows + 15) / 16), dim3(256), 0, st, xb, nullptr, gamma, beta, rows, c, eps, q, ldq, sc, lds);
+  else if (c <= 1024)
+    hipLaunchKernelGGL((layernorm_kernel<2, 2, true>), dim3((rows + 7) / 8), dim3(256), 0, st, xb, nullptr, gamma, beta, rows, c, eps, q, ldq, sc, lds);
+  else
+    hipLaunchKernelGGL((layernorm_kernel<4, 1, true>), dim3((rows + 3) / 4), dim3(256), 0, st, xb, nullptr, gamma, beta, rows, c, eps, q, ldq, sc, lds);
   TC_LAUNCH_CHECK();
   return TC_OK;
 }

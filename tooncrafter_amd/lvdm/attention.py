@@ -98,6 +98,10 @@ class FeedForward(PackedModule):
         w1, b1 = pack_geglu(self.net[0].proj.weight, self.net[0].proj.bias)
         return {"w1": w1, "b1": b1, "w2": pack_linear(self.net[2].weight), "b2": f32(self.net[2].bias)}
 
+    def ln_consumer(self):
+        """(packed weight, gated) of the GEMM that reads the LayerNorm in front of this block."""
+        return self.pk["w1"], True
+
     def forward(self, x_norm, residual):
         pk = self.pk
         g = ops.gemm(x_norm, pk["w1"], pk["b1"], act=ACT_GEGLU)
@@ -219,18 +223,21 @@ class BasicTransformerBlock(PackedModule):
         return {f"g{i}": f32(getattr(self, f"norm{i}").weight) for i in (1, 2, 3)} | \
                {f"b{i}": f32(getattr(self, f"norm{i}").bias) for i in (1, 2, 3)}
 
-    def _ln(self, x, i):
-        return ops.layernorm(x, self.pk[f"g{i}"], self.pk[f"b{i}"], 1e-5)
+    def _ln(self, x, i, consumer=None, gated=False):
+        """`consumer`: the packed weight of the single linear GEMM that reads the normalised rows (fused qkv, GEGLU
+        projection) -- lets the fp8 route have LayerNorm emit MXFP8 directly; ignored otherwise."""
+        mx_for = None if consumer is None else (consumer.shape[0], consumer.shape[0] // 2 if gated else consumer.shape[0])
+        return ops.layernorm(x, self.pk[f"g{i}"], self.pk[f"b{i}"], 1e-5, mx_for=mx_for)
 
     def forward_spatial(self, x, act: Act, ctx: ContextCache):
-        x = self.attn1.forward_spatial_self(self._ln(x, 1), x, act)
+        x = self.attn1.forward_spatial_self(self._ln(x, 1, self.attn1.pk["wqkv"]), x, act)
         x = self.attn2.forward_cross(self._ln(x, 2), x, act, ctx)
-        return self.ff(self._ln(x, 3), x)
+        return self.ff(self._ln(x, 3, *self.ff.ln_consumer()), x)
 
     def forward_temporal(self, x, act: Act):
-        x = self.attn1.forward_temporal_self(self._ln(x, 1), x, act)
-        x = self.attn2.forward_temporal_self(self._ln(x, 2), x, act)   # context=None -> self attention again
-        return self.ff(self._ln(x, 3), x)
+        x = self.attn1.forward_temporal_self(self._ln(x, 1, self.attn1.pk["wqkv"]), x, act)
+        x = self.attn2.forward_temporal_self(self._ln(x, 2, self.attn2.pk["wqkv"]), x, act)   # context=None -> self attention again
+        return self.ff(self._ln(x, 3, *self.ff.ln_consumer()), x)
 
 
 class SpatialTransformer(PackedModule):

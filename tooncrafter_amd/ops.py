@@ -60,6 +60,16 @@ def _dev(t: Optional[torch.Tensor], dtype, what: str, contiguous: bool = True):
     return t.data_ptr()
 
 
+class MxRows:
+    """An activation that exists only as MXFP8 (e4m3 bytes + E8M0 block scales): what `layernorm(..., mx_for=...)`
+    hands to the one GEMM that consumes it when the fp8 routing takes that GEMM."""
+
+    def __init__(self, q, scales, k):
+        self.q, self.scales, self.k = q, scales, k
+        self.shape = (q.shape[0], k)
+        self.device = q.device
+
+
 class HipOps:
     """The product backend: ctypes calls into libtooncrafter_hip.so."""
 
@@ -82,6 +92,7 @@ class HipOps:
         self.fp8_min_cin = int(os.environ.get("TC_FP8_MIN_CIN", "0"))
         self.fp8_min_m = 1024
         self.fp8_decoder = os.environ.get("TC_FP8_DECODER", "0") == "1"
+        self.fp8_fuse_ln = os.environ.get("TC_FP8_FUSE_LN", "1") != "0"     # LayerNorm emits MXFP8 for its fp8 consumer
         self.fp8_calls = {"mx": 0, "bf16": 0}
         self._wq = {}
 
@@ -100,7 +111,13 @@ class HipOps:
         w: [N, K] bf16 contiguous; conv: None | dict(kind='3x3'|'t3', frames, t_len, h_in, w_in,
         h_out, w_out, stride, upsample, cin); batch>1: a/w/out are the first batch item views
         and stride_* the element strides between items."""
-        a = _rows_view(a)
+        mx_a = a if isinstance(a, MxRows) else None
+        if mx_a is not None:
+            if conv is not None or out is not None or batch != 1 or self.fp8 is None:
+                raise ValueError("gemm: an MXFP8 activation feeds one plain linear GEMM of the fp8 route")
+            a = mx_a.q                                   # shape / device bookkeeping below; never read as bf16
+        else:
+            a = _rows_view(a)
         if w.dtype != BF16 or w.dim() != 2 or w.stride(1) != 1:
             raise ValueError("w must be a [N, K] bf16 tensor with unit column stride")
         _dev(w, BF16, "gemm: w", contiguous=False)
@@ -164,8 +181,10 @@ class HipOps:
         if self.fp8 is not None:
             if self._fp8_eligible(p, conv is not None, n_out, batch):
                 self.fp8_calls["mx"] += 1
-                self._gemm_mx(p, a, w)
+                self._gemm_mx(p, a, w, mx_a)
                 return out
+            if mx_a is not None:
+                raise ValueError("gemm: MXFP8 activation handed to a GEMM the fp8 route does not take")
             self.fp8_calls["bf16"] += 1
         nbytes = self.lib.tc_gemm_workspace(C.byref(p))          # > 0 only for split-K candidates (low-res layers)
         if nbytes > 0:
@@ -224,10 +243,15 @@ class HipOps:
             return self.fp8 in ("all", "conv", kind) and p.cin % 64 == 0 and self.fp8_min_cin <= p.cin <= self.fp8_max_cin
         return self.fp8 in ("all", "linear") and p.k >= self.fp8_min_k and p.n >= self.fp8_min_n
 
-    def _gemm_mx(self, p, a, w):
+    def _gemm_mx(self, p, a, w, mx_a=None):
         kc = p.cin if p.gather != GATHER_LINEAR else p.k
         rows = p.frames * p.h_in * p.w_in if p.gather == GATHER_CONV3x3 else p.m
-        aq, asc = self.quant_mxfp8(a[:rows], kc)
+        if mx_a is not None:
+            if mx_a.k != kc:
+                raise ValueError(f"gemm: MXFP8 activation has K = {mx_a.k}, weight K = {kc}")
+            aq, asc = mx_a.q, mx_a.scales
+        else:
+            aq, asc = self.quant_mxfp8(a[:rows], kc)
         wq, wsc = self._weight_mx(w)
         px = TcGemmMxParams()
         px.g = p
@@ -305,13 +329,26 @@ class HipOps:
                    "tc_groupnorm")
         return y
 
-    def layernorm(self, x, gamma, beta, eps=1e-5):
+    def layernorm(self, x, gamma, beta, eps=1e-5, mx_for=None):
+        """`mx_for` = (N, N_out) of the packed weight of the ONE linear GEMM that consumes the result: when the fp8
+        route takes that GEMM the row leaves as MXFP8 (an `MxRows`; the quantiser fused into its producer)."""
         x = _rows_view(x)
         if not x.is_contiguous():
             raise ValueError("layernorm: x must be contiguous")
         if gamma.numel() != x.shape[1] or beta.numel() != x.shape[1]:
             raise ValueError("layernorm: gamma/beta must have C elements")
         gp, bp = _dev(gamma, torch.float32, "layernorm: gamma"), _dev(beta, torch.float32, "layernorm: beta")
+        if mx_for is not None and self.fp8 is not None and self.fp8_fuse_ln:
+            probe = TcGemmParams()
+            probe.m, probe.n, probe.k, probe.gather = x.shape[0], mx_for[0], x.shape[1], GATHER_LINEAR
+            if self._fp8_eligible(probe, False, mx_for[1], 1):
+                rows, k = x.shape
+                lds = (k + 127) // 128 * 4
+                q = torch.empty((rows, k), dtype=torch.uint8, device=x.device)
+                sc = torch.empty((rows, lds), dtype=torch.uint8, device=x.device)
+                _lib.check(self.lib.tc_layernorm_mxfp8(x.data_ptr(), q.data_ptr(), k, sc.data_ptr(), lds, gp, bp, rows, k,
+                                                       float(eps), _stream()), "tc_layernorm_mxfp8")
+                return MxRows(q, sc, k)
         y = torch.empty_like(x)
         _lib.check(self.lib.tc_layernorm(x.data_ptr(), y.data_ptr(), gp, bp,
                                          x.shape[0], x.shape[1], float(eps), _stream()), "tc_layernorm")

@@ -80,7 +80,9 @@ class TorchLibOps(HipOps):
     def groupnorm(self, x, gamma, beta, *, samples, rows, eps, silu=False):
         return self.t.groupnorm(x, gamma, beta, samples, rows, float(eps), bool(silu))
 
-    def layernorm(self, x, gamma, beta, eps=1e-5):
+    def layernorm(self, x, gamma, beta, eps=1e-5, mx_for=None):
+        if mx_for is not None and self.fp8 is not None:
+            return super().layernorm(x, gamma, beta, eps, mx_for=mx_for)
         return self.t.layernorm(x, gamma, beta, float(eps))
 
     def ddim_step(self, x, e_cond, e_uncond, noise, *, cfg_scale, guidance_rescale, sqrt_ac, sqrt_1m_ac, sqrt_a_prev,
