@@ -55,9 +55,9 @@ def run(label, mode, **attrs):
 
 
 run("bf16 (no fp8)", None)
-run("TC_FP8=1 (default rule)", "all")
+run("TC_FP8=all", "all")
 run("convolutions only", "conv")
-run("linear only (K >= 640, N >= 1280)", "linear")
+run("TC_FP8=1: linear only (K >= 640, N >= 1280)", "linear")
 run("convolutions with cin >= 640 only", "conv", fp8_min_cin=640)
 run("convolutions with cin <= 640 only", "conv", fp8_max_cin=640)
 run("convolutions except the input convolution (cin >= 320)", "conv", fp8_min_cin=320)
@@ -65,3 +65,6 @@ run("3x3 convolutions only, cin >= 320", "conv3", fp8_min_cin=320)
 run("temporal convolutions only", "convt")
 run("all, convolutions cin >= 320", "all", fp8_min_cin=320)
 run("every eligible linear (K >= 320, any N)", "linear", fp8_min_k=320, fp8_min_n=0)
+run("wide-N linear incl. level 0 (K >= 320, N >= 960)", "linear", fp8_min_k=320, fp8_min_n=960)
+run("wide-N linear incl. level 0 (K >= 320, N >= 1280)", "linear", fp8_min_k=320, fp8_min_n=1280)
+run("linear default, LayerNorm fusion off", "linear", fp8_fuse_ln=False)
