@@ -57,14 +57,15 @@ def run(label, mode, **attrs):
 run("bf16 (no fp8)", None)
 run("TC_FP8=all", "all")
 run("convolutions only", "conv")
-run("TC_FP8=1: linear only (K >= 640, N >= 1280)", "linear")
+run("TC_FP8=1: linear, K >= 640, N >= 1280, N >= 2 K", "linear")
+run("linear, K >= 640, N >= 1280 (no N >= 2 K rule)", "linear", fp8_n_over_k=0.0)
 run("convolutions with cin >= 640 only", "conv", fp8_min_cin=640)
 run("convolutions with cin <= 640 only", "conv", fp8_max_cin=640)
 run("convolutions except the input convolution (cin >= 320)", "conv", fp8_min_cin=320)
 run("3x3 convolutions only, cin >= 320", "conv3", fp8_min_cin=320)
 run("temporal convolutions only", "convt")
 run("all, convolutions cin >= 320", "all", fp8_min_cin=320)
-run("every eligible linear (K >= 320, any N)", "linear", fp8_min_k=320, fp8_min_n=0)
+run("every eligible linear (K >= 320, any N)", "linear", fp8_min_k=320, fp8_min_n=0, fp8_n_over_k=0.0)
 run("wide-N linear incl. level 0 (K >= 320, N >= 960)", "linear", fp8_min_k=320, fp8_min_n=960)
 run("wide-N linear incl. level 0 (K >= 320, N >= 1280)", "linear", fp8_min_k=320, fp8_min_n=1280)
 run("linear default, LayerNorm fusion off", "linear", fp8_fuse_ln=False)

@@ -31,7 +31,7 @@ def timed(fn, reps=REPS):
 def main():
     h = HipOps()
     h8 = HipOps()
-    h8.fp8, h8.fp8_min_k, h8.fp8_min_m, h8.fp8_min_n, h8.fp8_max_cin = "all", 0, 1, 0, 1 << 20
+    h8.fp8, h8.fp8_min_k, h8.fp8_min_m, h8.fp8_min_n, h8.fp8_max_cin, h8.fp8_n_over_k = "all", 0, 1, 0, 1 << 20, 0.0
     cases = [
         ("L0 conv3x3 320->320 (B=2)", dict(frames=32, h=40, w=64, cin=320, cout=320)),
         ("L1 conv3x3 640->640", dict(frames=32, h=20, w=32, cin=640, cout=640)),

@@ -71,6 +71,8 @@ def test_fp8_routing_rule(monkeypatch):
         return p
     assert h._fp8_eligible(prm(20480, 1920, 640), False, 1920, 1)            # level-1 qkv: wide N
     assert not h._fp8_eligible(prm(81920, 320, 1280), False, 320, 1)         # ff2: the quantiser costs more than it saves
+    assert not h._fp8_eligible(prm(5120, 1280, 5120), False, 1280, 1)        # level-2 ff2 / out-projection: N < 2 K
+    assert not h._fp8_eligible(prm(5120, 1280, 1280), False, 1280, 1)
     assert not h._fp8_eligible(prm(81920, 960, 320), False, 960, 1)          # short K
     assert not h._fp8_eligible(prm(20480, 1920, 640), False, 1920, 2)        # batched
     assert not h._fp8_eligible(prm(77, 2048, 1024), False, 2048, 1)          # a handful of rows (context projections)

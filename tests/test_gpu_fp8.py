@@ -28,7 +28,7 @@ DEV = "cuda"
 def hip8():
     from tooncrafter_amd.ops import HipOps
     h = HipOps()
-    h.fp8, h.fp8_min_k, h.fp8_min_m, h.fp8_min_n, h.fp8_max_cin = "all", 0, 1, 0, 1 << 20
+    h.fp8, h.fp8_min_k, h.fp8_min_m, h.fp8_min_n, h.fp8_max_cin, h.fp8_n_over_k = "all", 0, 1, 0, 1 << 20, 0.0
     return h
 
 

@@ -62,7 +62,7 @@ def test_torch_ops_match_ctypes_binding_bitwise(both):
     assert torch.equal(aq_t, aq_c) and torch.equal(as_t, as_c)
     wq, ws = t.quant_mxfp8(w, 320)
     y_t = t.t.gemm_mx(aq_t, as_t, wq, ws, b, res, None, 0, ACT_NONE, 1.0, 1.0, False, [])
-    c.fp8, c.fp8_min_k, c.fp8_min_n, c.fp8_min_m = "linear", 0, 0, 1
+    c.fp8, c.fp8_min_k, c.fp8_min_n, c.fp8_min_m, c.fp8_n_over_k = "linear", 0, 0, 1, 0.0
     try:
         assert torch.equal(y_t, c.gemm(a, w, b, residual=res))
     finally:

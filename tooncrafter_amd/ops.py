@@ -90,6 +90,7 @@ class HipOps:
         self.fp8_min_n = int(os.environ.get("TC_FP8_MIN_N", "1280"))
         self.fp8_max_cin = int(os.environ.get("TC_FP8_MAX_CIN", "1280"))
         self.fp8_min_cin = int(os.environ.get("TC_FP8_MIN_CIN", "0"))
+        self.fp8_n_over_k = float(os.environ.get("TC_FP8_N_OVER_K", "2"))
         self.fp8_min_m = 1024
         self.fp8_decoder = os.environ.get("TC_FP8_DECODER", "0") == "1"
         self.fp8_fuse_ln = os.environ.get("TC_FP8_FUSE_LN", "1") != "0"     # LayerNorm emits MXFP8 for its fp8 consumer
@@ -237,11 +238,14 @@ class HipOps:
             return False
         # measured (profiles/r02_mx_gemm_bench.txt): with the activation quantiser in front, fp8 pays on the 3x3 /
         # temporal convolutions up to cin = 1280 (one quantisation feeds 9 / 3 taps) and on linear layers whose N is
-        # large against K (qkv, GEGLU); short-K or narrow-N linear layers lose to the extra pass and stay bf16
+        # large against K (qkv, GEGLU: N >= 2 K -- exactly the consumers of a LayerNorm, which then emits MXFP8
+        # itself); short-K or narrow-N linear layers (out-projections, ff2: slower in fp8 even before the quantiser
+        # pass, profiles/r02_mx_gemm_bench.txt) stay bf16
         if is_conv:
             kind = "conv3" if p.gather == GATHER_CONV3x3 else "convt"
             return self.fp8 in ("all", "conv", kind) and p.cin % 64 == 0 and self.fp8_min_cin <= p.cin <= self.fp8_max_cin
-        return self.fp8 in ("all", "linear") and p.k >= self.fp8_min_k and p.n >= self.fp8_min_n
+        return self.fp8 in ("all", "linear") and p.k >= self.fp8_min_k and p.n >= self.fp8_min_n \
+            and p.n >= self.fp8_n_over_k * p.k
 
     def _gemm_mx(self, p, a, w, mx_a=None):
         kc = p.cin if p.gather != GATHER_LINEAR else p.k
