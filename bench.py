@@ -549,6 +549,9 @@ def main():
         result["frames_per_s_with_encoder"] = round(16.0 / (dt / args.steps / clips_per_step + enc_ms * 1e-3), 4)
     if rank == 0 and not args.no_roofline:
         result["roofline"] = measure_roofline(model, inps[0])
+        if args.fp8:
+            result["roofline"]["note"] = ("--fp8: the timed launches include the routed tc_gemm_mxfp8 ones; FLOPs are priced "
+                                          "against the bf16 peak all the same (dense MX fp8 peak: ~4.66 PF/s measured)")
         _log("roofline done")
         result["roofline_hbm"] = measure_roofline_hbm(model, inps[0])
         _log("roofline_hbm done")
