@@ -428,7 +428,8 @@ def main():
     ap.add_argument("--batched-decode", type=int, default=0, metavar="B",
                     help="configs[3]: B clips per GPU per step, decoded in one call (perframe_ae=False)")
     ap.add_argument("--fp8", action="store_true",
-                    help="configs[4]: MXFP8 (e4m3 + E8M0 block scales) operands on the eligible GEMMs / convolutions")
+                    help="configs[4]: MXFP8 (e4m3 + E8M0 block scales) operands on the qkv / GEGLU projections (TC_FP8=1; "
+                         "export TC_FP8=all to add the convolutions)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
