@@ -225,49 +225,92 @@ def measure_roofline_hbm(model, inp):
             un(None, ts, context=ctx2, fs=fs2, x_parts=[x2, cc2])
         n, ms, by = probe.summary()
     gbs = by / (ms * 1e-3) / 1e9
+    name, tj = _pmc_file("r03_pmc_gn_traffic.json")
+    traffic = round(tj["traffic_bytes_per_launch"]) if tj is not None else None
     return {"bound": "hbm", "kernel": "tc_groupnorm (GroupNorm32 + SiLU over channels-last rows)",
             "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-            "traffic": None, "launches": n, "avg_launch_us": round(ms * 1e3 / max(n, 1), 2),
+            "traffic": traffic,
+            "traffic_source": None if tj is None else f"profiles/{name}: (2*FETCH_SIZE + WRITE_SIZE) per tc_groupnorm call "
+                                                      "of a B=2 UNet forward; a committed counter run",
+            "launches": n, "avg_launch_us": round(ms * 1e3 / max(n, 1), 2),
             "algorithmic_gb_per_unet_fwd_b2": round(by / 1e9, 3), "ms_per_unet_fwd_b2": round(ms, 3)}
 
 
+def _pmc_file(*names):
+    pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    for name in names:
+        tp = os.path.join(pdir, name)
+        if os.path.exists(tp):
+            with open(tp) as f:
+                return name, json.load(f)
+    return None, None
+
+
 def measure_roofline(model, inp):
+    """GEMM family (tc_gemm_bf16: every Linear / implicit-GEMM convolution launch) over ONE CLIP: 50 batched-CFG
+    B=2 UNet forwards + the 16-frame decode + the 14-frame re-decode.  One forward and one of each decode are
+    bracketed launch by launch with HIP events on the launch stream (eager, so that every launch is visible);
+    the clip figure composes them with the unit counts (50, 1, 1)."""
     un = model.model.diffusion_model
+    dec = model.first_stage_model.decoder
     x2 = torch.cat([inp["x_T"]] * 2)
     cc2 = torch.cat([inp["c_concat"]] * 2)
     ctx2 = torch.cat([inp["cond"], inp["uncond"]])
     ts = torch.full((2,), 499, device=x2.device, dtype=torch.long)
     fs2 = torch.cat([inp["fs"]] * 2)
-    with torch.no_grad():
-        un(None, ts, context=ctx2, fs=fs2, x_parts=[x2, cc2])          # warm (context K/V cached)
-        torch.cuda.synchronize()
-        # give the host a head start so that event gaps are not launch-bound
+    z16 = torch.randn(1, 4, 16, 40, 64, device=x2.device)
+    z14 = z16[:, :, [i for i in range(16) if i not in (1, 14)]].contiguous()
+
+    def head_start():       # give the host a head start so that event gaps are not launch-bound
         big = torch.empty((8192, 8192), device=x2.device, dtype=torch.bfloat16).normal_()
         for _ in range(6):
             big @ big
-        with GemmProbe(ops.backend()) as probe:
-            un(None, ts, context=ctx2, fs=fs2, x_parts=[x2, cc2])
-        n, ms, fl = probe.summary()
+
+    def probe(fn):
+        fn()                                                            # warm (context / reference K/V cached)
+        torch.cuda.synchronize()
+        head_start()
+        with GemmProbe(ops.backend()) as pr:
+            fn()
+        return pr.summary()
+
+    was = dec.use_hipgraph
+    dec.use_hipgraph = False
+    try:
+        with torch.no_grad():
+            n_f, ms_f, fl_f = probe(lambda: un(None, ts, context=ctx2, fs=fs2, x_parts=[x2, cc2]))
+            n_16, ms_16, fl_16 = probe(lambda: dec.decode_clip(z16, inp["refs"], scale=1.0 / 0.18215))
+            n_14, ms_14, fl_14 = probe(lambda: dec.decode_clip(z14, inp["refs"], scale=1.0 / 0.18215))
+    finally:
+        dec.use_hipgraph = was
+    n = 50 * n_f + n_16 + n_14
+    ms = 50 * ms_f + ms_16 + ms_14
+    fl = 50 * fl_f + fl_16 + fl_14
     achieved = fl / (ms * 1e-3) / 1e12
+    unet_tfs = fl_f / (ms_f * 1e-3) / 1e12
+    dec_tfs = (fl_16 + fl_14) / ((ms_16 + ms_14) * 1e-3) / 1e12
     # HBM-side bytes per launch come from a separate rocprofv3 --pmc run of the same forward (counters cannot
     # be read from inside this process); the committed summary of that run is quoted with its provenance
     traffic, traffic_src = None, None
-    pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for name in ("r02_pmc_unet_traffic.json", "r01_v6_pmc_unet_traffic.json"):            # newest committed counter run
-        tp = os.path.join(pdir, name)
-        if os.path.exists(tp):
-            with open(tp) as f:
-                tj = json.load(f)
-            traffic = round(tj["traffic_bytes_per_launch"])
-            traffic_src = (f"profiles/{name}: (2*FETCH_SIZE + WRITE_SIZE) per tc_gemm_bf16 launch, bytes; L2-miss "
-                           "(fabric) traffic incl. Infinity-Cache hits; %.1f GB per B=2 forward vs 43.2 GB algorithmic"
-                           % (tj["traffic_bytes_per_forward"] / 1e9))
-            break
-    return {"bound": "mfma", "kernel": "gemm_kernel (tc_gemm_bf16: Linear / implicit-GEMM conv, all gather modes)",
+    name, tj = _pmc_file("r03_pmc_unet_traffic.json", "r02_pmc_unet_traffic.json", "r01_v6_pmc_unet_traffic.json")
+    if tj is not None:
+        traffic = round(tj["traffic_bytes_per_launch"])
+        traffic_src = (f"profiles/{name}: (2*FETCH_SIZE + WRITE_SIZE) per tc_gemm_bf16 launch of a B=2 UNet forward, bytes; "
+                       "L2-miss (fabric) traffic incl. Infinity-Cache hits; %.1f GB per B=2 forward vs 43.2 GB algorithmic; "
+                       "a committed counter run, not measured in this process" % (tj["traffic_bytes_per_forward"] / 1e9))
+    return {"bound": "mfma", "kernel": "tc_gemm_bf16 family (gemm_kernel / gemm16 / gemm_wide / gemm_ws: Linear and "
+                                       "implicit-GEMM convolutions, all gather modes), UNet + decoder launches of one clip",
             "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "launches": n, "avg_launch_us": round(ms * 1e3 / max(n, 1), 2),
-            "algorithmic_tflop_per_unet_fwd_b2": round(fl / 1e12, 3), "gemm_ms_per_unet_fwd_b2": round(ms, 3)}
+            "composition": "50 x (B=2 UNet forward) + decode 16f + decode 14f",
+            "algorithmic_tflop_per_clip_gemm": round(fl / 1e12, 2), "gemm_ms_per_clip": round(ms, 1),
+            "unet": {"launches": n_f, "algorithmic_tflop_per_unet_fwd_b2": round(fl_f / 1e12, 3),
+                     "gemm_ms_per_unet_fwd_b2": round(ms_f, 3), "achieved": round(unet_tfs, 2),
+                     "frac": round(unet_tfs / PEAK_BF16_TFLOPS, 4)},
+            "decoder": {"launches": n_16 + n_14, "algorithmic_tflop_16f_plus_14f": round((fl_16 + fl_14) / 1e12, 3),
+                        "gemm_ms_16f_plus_14f": round(ms_16 + ms_14, 3), "achieved": round(dec_tfs, 2),
+                        "frac": round(dec_tfs / PEAK_BF16_TFLOPS, 4)}}
 
 
 def measure_boundary(model, inp):
@@ -381,24 +424,32 @@ def self_launch(args):
 
 
 def supervise(args):
-    """Single-GPU runs are supervised: the measurement runs in a child process; if that process is KILLED by a GPU memory
-    fault (some leases of the pool abort any sustained job, DESIGN.md section 7 -- a fault cannot be caught in-process)
-    the identical measurement is started again in a fresh process, up to three attempts.  The JSON line is the child's,
-    plus `attempts`; a run that completes is never repeated, so the number reported is always one whole measurement."""
+    """`--retry` only (off by default: a fault in the default run is a FAILED run, exit code and stderr intact).
+    The measurement runs in a child process; if that process dies WITHOUT a result, scripts/gpu_health.py (plain
+    PyTorch, none of this repo's code loaded) decides: box unhealthy -> the identical measurement is started again
+    in a fresh process (up to three attempts); box healthy -> the failure is the code's, it is reported with the
+    child's stderr and NOT retried.  A result from attempt > 1 carries `attempts` and `flagged`."""
     import subprocess
-    last = ""
+    argv = [a for a in sys.argv[1:] if a != "--retry"]
     for attempt in (1, 2, 3):
-        r = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--child"],
-                           stdout=subprocess.PIPE, text=True)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True)
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode == 0 and lines:
             d = json.loads(lines[-1])
             d["attempts"] = attempt
+            if attempt > 1:
+                d["flagged"] = f"{attempt - 1} earlier attempt(s) died on a lease whose plain-PyTorch health check also failed"
             print(json.dumps(d))
             return 0
-        last = r.stdout[-2000:]
         sys.stderr.write(f"[bench] attempt {attempt} ended with exit code {r.returncode} without a result\n")
-    sys.stderr.write(last)
+        sys.stderr.write(r.stderr[-3000:])
+        hc = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gpu_health.py")], capture_output=True, text=True)
+        if hc.returncode == 0:
+            sys.stderr.write("[bench] scripts/gpu_health.py PASSES on this lease: the failure is this code's, not retried. "
+                             "Re-run with TC_DEBUG_SYNC=1 to name the faulting entry point.\n")
+            return r.returncode or 1
+        sys.stderr.write("[bench] scripts/gpu_health.py also fails on this lease (box unhealthy): retrying\n")
     return 1
 
 
@@ -422,8 +473,8 @@ def launcher_selftest(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--batched-decode", type=int, default=0, metavar="B",
                     help="configs[3]: B clips per GPU per step, decoded in one call (perframe_ae=False)")
@@ -433,8 +484,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--no-retry", action="store_true", help="run in this process; no supervised retry")
+    ap.add_argument("--retry", action="store_true",
+                    help="supervise the run in a child process and repeat it ONLY if the lease itself is unhealthy "
+                         "(scripts/gpu_health.py fails); off by default")
+    ap.add_argument("--no-retry", action="store_true", help=argparse.SUPPRESS)      # accepted for old command lines
     args = ap.parse_args()
 
     if args.fp8:
@@ -443,7 +496,7 @@ def main():
         sys.exit(self_launch(args))
     if args.launcher_selftest:
         return launcher_selftest(args)
-    if args.gpus == 1 and "WORLD_SIZE" not in os.environ and not args.child and not args.no_retry:
+    if args.retry and args.gpus == 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(supervise(args))
 
     from tooncrafter_amd import dist as tcdist
@@ -465,8 +518,12 @@ def main():
     if bdec > 0:
         for j in (0, bdec):
             inps[j]["refs_batched"] = [torch.cat([inps[j + i]["refs"][l] for i in range(bdec)], 0) for l in range(5)]
-    shape = (clips_per_step, 3, 16, 320, 512)
-    gather_buf = [torch.empty(shape, device=device) for _ in range(world)] if rank == 0 and world > 1 else None
+    # what leaves a GPU is the writer-side uint8 clip (inference.py:146-153 on the device, tc_video_to_u8): 7.9 MB per
+    # clip over xGMI instead of 31.5 MB fp32.  Every rank converts, also at N = 1 (equal work per GPU at every N).
+    from tooncrafter_amd import output as tcout
+    shape = (clips_per_step, 16, 320, 512, 3)
+    gather_buf = [torch.empty(shape, device=device, dtype=torch.uint8) for _ in range(world)] \
+        if rank == 0 and world > 1 else None
     counter = [0]
 
     def step():
@@ -477,7 +534,8 @@ def main():
                 video = run_clips_batched_decode(model, sampler, inps[k * bdec:(k + 1) * bdec], args.ddim_steps)
             else:
                 video = run_clip(model, sampler, inps[k], args.ddim_steps)
-            tcdist.gather_clips(video, dst=0, out=gather_buf)       # the one collective of the path
+            frames_u8 = tcout.clip_to_uint8(video)                       # (b, T, H, W, 3) uint8, on the device
+            tcdist.gather_clips(frames_u8, dst=0, out=gather_buf)       # the one collective of the path
         return video
 
     def fence():
@@ -534,6 +592,11 @@ def main():
             for name, a, b in STAGE_EVENTS:
                 acc[name] = acc.get(name, 0.0) + a.elapsed_time(b)
             result["stage_ms_per_clip"] = {k: round(v / args.steps, 2) for k, v in acc.items()}
+    if world > 1:
+        # the measurement is over: release the other ranks now -- what follows (encoder timing, roofline probes) is
+        # rank 0 alone and must not sit inside anybody's collective timeout
+        dist.barrier()
+        dist.destroy_process_group()
     if rank == 0:
         # row f1 (not part of `value`): the first-stage encoder that produces z and the reference
         # hidden states, 16 frames at 320x512, reported so that "with encoder" can be derived
@@ -560,9 +623,6 @@ def main():
         _log("boundary done")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(model, inps[0])
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
 

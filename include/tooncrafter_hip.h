@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TC_ABI_VERSION 7
+#define TC_ABI_VERSION 8
 
 enum {
   TC_OK = 0,
@@ -85,6 +85,13 @@ typedef struct TcGemmParams {
    * and applies the epilogue (bit-reproducible).  NULL / too small = never split. */
   void* workspace;
   int64_t workspace_bytes;
+  /* ABI 8 -- LayerNorm of the A rows as a prologue of the product (lvdm/modules/attention.py:225-227 in front of the
+   * qkv / GEGLU projections, attention.py:242-246): a_norm = 1 normalises every row over its k columns,
+   * (x - mean) * rsqrt(var + a_norm_eps) with fp32 statistics, before it is multiplied; the affine part is the
+   * CALLER's job (w[n, :] *= gamma, bias += w @ beta: exact in real arithmetic).  Only problems tc_gemm_ws_eligible
+   * accepts can carry it (whole rows of A must sit in one block); tc_gemm_bf16 returns TC_ESHAPE otherwise. */
+  int32_t a_norm;
+  float a_norm_eps;
 } TcGemmParams;
 
 /* C = epilogue(gather(A) * W^T), bf16 MFMA, fp32 accumulate.
@@ -96,6 +103,9 @@ typedef struct TcGemmParams {
 int tc_gemm_bf16(const TcGemmParams* p, void* stream);
 /* bytes of TcGemmParams.workspace this problem would use (0: it is not a split-K candidate) */
 int64_t tc_gemm_workspace(const TcGemmParams* p);
+/* ABI 8 -- 1 if tc_gemm_bf16 would run this problem on the weight-stationary K = 320 kernel (csrc/gemm_ws.hip), the
+ * only one that accepts a_norm = 1: the host asks BEFORE it decides to drop a LayerNorm launch. */
+int tc_gemm_ws_eligible(const TcGemmParams* p);
 
 /* ABI 7 -- MX block-scaled fp8 GEMM (BASELINE.json configs[4]: the CDNA4 fp8 MFMA GEMM path).
  * Operands are OCP MX "MXFP8": e4m3 elements with one E8M0 (power-of-two) scale per 32 consecutive K

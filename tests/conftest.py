@@ -84,3 +84,41 @@ def rel_l2(a, b):
     a = a.double().flatten()
     b = b.double().flatten()
     return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+# ---------------------------------------------------------------- full-size fixtures (BASELINE.json configs[1] shapes)
+# Session-scoped: the 1.44 B-parameter model is synthesised once for tests/test_gpu_fullsize.py and
+# tests/test_gpu_ddim50.py.
+@pytest.fixture(scope="session")
+def golden():
+    import fullsize_cases as fc
+    if not os.path.exists(fc.GOLDEN_FILE):
+        pytest.fail(f"{fc.GOLDEN_FILE} missing: run tests/golden/make_fullsize_golden.py")
+    return dict(np.load(fc.GOLDEN_FILE))
+
+
+@pytest.fixture(scope="session")
+def inp():
+    import fullsize_cases as fc
+    return fc.inputs()
+
+
+@pytest.fixture(scope="session")
+def full_model():
+    """LatentVisualDiffusion at the full widths on the HIP backend, parameters drawn on the CPU generator (the values the
+    oracle goldens were made with), one tensor at a time."""
+    import bench
+    from tooncrafter_amd import ops, synth
+    from tooncrafter_amd.utils import instantiate_from_config
+    assert ops.backend().name == "hip"
+    with torch.device("meta"):
+        model = instantiate_from_config(dict(target="lvdm.models.ddpm3d.LatentVisualDiffusion",
+                                             params=bench.MODEL_PARAMS))
+    model = model.to_empty(device="cuda").eval()
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            p.copy_(synth.synth_tensor(name, tuple(p.shape), 1234, "cpu"))
+        bufs = bench.instantiate_schedule()
+        for name, b in model.named_buffers():
+            b.copy_(bufs[name].to("cuda"))
+    return model

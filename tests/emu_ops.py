@@ -22,8 +22,13 @@ def _f(t):
 class EmuOps:
     name = "emu"
 
-    def __init__(self, round_bf16=True):
+    def __init__(self, round_bf16=True, ln_fusion_k=None):
         self.round = round_bf16
+        self.ln_fusion_k = ln_fusion_k       # tests only: accept a_norm_eps for this K (the HIP library: K = 320, M >= 8192)
+        self.ln_fused_calls = 0
+
+    def gemm_ln_eligible(self, m, n, k, *, geglu=False, lda=None):
+        return self.ln_fusion_k is not None and k == self.ln_fusion_k
 
     def _out(self, x, f32=False):
         if f32:
@@ -56,7 +61,7 @@ class EmuOps:
 
     def gemm(self, a, w, bias=None, *, act=ACT_NONE, residual=None, row_bias=None, row_div=0, alpha=1.0,
              out_scale=1.0, out=None, out_f32=False, conv=None, batch=1, stride_a=0, stride_w=0, stride_c=0,
-             m=None):
+             m=None, a_norm_eps=None):
         n, k = w.shape
         if batch > 1:
             assert conv is None and residual is None and row_bias is None
@@ -71,6 +76,14 @@ class EmuOps:
         A = self._gather(a, conv, k)
         if m is not None:
             A = A[:m]
+        if a_norm_eps is not None:
+            # ABI 8: rows normalised over K (fp32 statistics, biased variance) and rounded to bf16 -- the tile the MFMAs
+            # read; the affine half of the LayerNorm is already inside w / bias (common.fold_layernorm)
+            assert conv is None
+            mu = A.mean(1, keepdim=True)
+            A = (A - mu) * torch.rsqrt(((A - mu) ** 2).mean(1, keepdim=True) + a_norm_eps)
+            A = _f(A.to(BF16)) if self.round else A
+            self.ln_fused_calls += 1
         acc = (A @ _f(w).t()) * alpha
         if act == ACT_GEGLU:
             # rows packed per 32: [16 values | 16 gates]

@@ -37,42 +37,6 @@ DEC_STAGE_FLOOR = {"mid": 4.78e-3, "level3": 4.91e-3, "level2": 7.98e-3, "level1
 DDIM_X0_FLOOR, DDIM_FINAL_FLOOR = (7.144e-2, 6.283e-2, 4.530e-2), 4.523e-2
 
 
-@pytest.fixture(scope="module")
-def golden():
-    if not os.path.exists(fc.GOLDEN_FILE):
-        pytest.fail(f"{fc.GOLDEN_FILE} missing: run tests/golden/make_fullsize_golden.py")
-    return dict(np.load(fc.GOLDEN_FILE))
-
-
-@pytest.fixture(scope="module")
-def inp():
-    return fc.inputs()
-
-
-def _fill_from_cpu_synth(module, prefix):
-    """Parameters drawn on the CPU generator (the values the oracle golden was made with), one tensor at a time."""
-    with torch.no_grad():
-        for name, p in module.named_parameters():
-            p.copy_(synth.synth_tensor(prefix + name, tuple(p.shape), 1234, "cpu"))
-
-
-@pytest.fixture(scope="module")
-def full_model():
-    import bench
-    from tooncrafter_amd.utils import instantiate_from_config
-    assert ops.backend().name == "hip"
-    with torch.device("meta"):
-        model = instantiate_from_config(dict(target="lvdm.models.ddpm3d.LatentVisualDiffusion",
-                                             params=bench.MODEL_PARAMS))
-    model = model.to_empty(device=DEV).eval()
-    _fill_from_cpu_synth(model, "")
-    bufs = bench.instantiate_schedule()
-    with torch.no_grad():
-        for name, b in model.named_buffers():
-            b.copy_(bufs[name].to(DEV))
-    return model
-
-
 def cosine(a, b):
     a, b = a.double().flatten(), b.double().flatten()
     return float((a @ b) / (a.norm() * b.norm()))

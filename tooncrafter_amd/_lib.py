@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libtooncrafter_hip.so")
 
-TC_ABI_VERSION = 7
+TC_ABI_VERSION = 8
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_GEGLU = 0, 1, 2, 3
 GATHER_LINEAR, GATHER_CONV3x3, GATHER_CONVT3 = 0, 1, 2
 
@@ -34,6 +34,7 @@ class TcGemmParams(C.Structure):
         ("batch", C.c_int32),
         ("stride_a", C.c_int64), ("stride_w", C.c_int64), ("stride_c", C.c_int64),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("a_norm", C.c_int32), ("a_norm_eps", C.c_float),
     ]
 
 
@@ -97,6 +98,7 @@ SYMBOLS = {
     "tc_video_to_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "tc_ddim_workspace": (C.c_int64, [C.c_int32]),
     "tc_ddim_step": (C.c_int, [C.POINTER(TcDdimParams), C.c_void_p, C.c_int64, C.c_void_p]),
+    "tc_gemm_ws_eligible": (C.c_int, [C.POINTER(TcGemmParams)]),
     "tc_abi_version": (C.c_int, []),
     "tc_build_info": (C.c_char_p, []),
 }

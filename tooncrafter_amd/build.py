@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtooncrafter_hip.so")
-SOURCES = ["gemm.hip", "gemm_wide.hip", "gemm16.hip", "gemm_mx.hip", "attention.hip", "norm.hip", "elementwise.hip"]
+SOURCES = ["gemm.hip", "gemm_wide.hip", "gemm16.hip", "gemm_ws.hip", "gemm_mx.hip", "attention.hip", "norm.hip", "elementwise.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "gemm_epilogue.h"),
            os.path.join(ROOT, "include", "tooncrafter_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on",
@@ -77,9 +77,10 @@ def build_torch_ops(force: bool = False, verbose: bool = True) -> str:
     if not cxx:
         raise RuntimeError("no host C++ compiler for the torch operator layer")
     tlib = ce.library_paths()[0]
+    rocm = os.environ.get("ROCM_PATH") or getattr(ce, "ROCM_HOME", None) or "/opt/rocm"
     cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
            f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
-           *["-I" + p for p in ce.include_paths()], "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
+           *["-I" + p for p in ce.include_paths()], "-I" + os.path.join(rocm, "include"), "-I" + os.path.join(ROOT, "include"),
            TORCH_SRC, "-o", TORCH_LIB, "-L" + tlib, "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_hip",
            "-L" + HERE, "-ltooncrafter_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + tlib]
     if verbose:

@@ -332,6 +332,11 @@ extern "C" int tc_gemm_bf16(const TcGemmParams* pp, void* stream) {
     const int v = atoi(e);
     return (v == 22 || v == 21 || v == 12 || v == 11) ? v : 0;
   }();
+  if (force == 0 && tc_gemm_ws_try(p, batch, s)) {                     // K = 320 linear layers of level 0: W in registers
+    TC_LAUNCH_CHECK();
+    return TC_OK;
+  }
+  if (p.a_norm) return TC_ESHAPE;                                      // only the weight-stationary kernel normalises A rows
   if (force == 0 && tc_gemm_tile16_try(p, batch, s)) {                 // widths 320 k at levels 0 / 1: 160x160 tiles
     TC_LAUNCH_CHECK();
     return TC_OK;

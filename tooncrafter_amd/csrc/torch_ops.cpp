@@ -89,7 +89,7 @@ void fill_gemm(TcGemmParams& p, const Tensor& a, const GemmGeom& g, Tensor& out,
 
 Tensor gemm_cuda(const Tensor& a, const Tensor& w, const optional<Tensor>& bias, const optional<Tensor>& residual,
                  const optional<Tensor>& row_bias, int64_t row_div, int64_t act, double alpha, double out_scale,
-                 bool out_f32, at::IntArrayRef conv) {
+                 bool out_f32, at::IntArrayRef conv, double a_norm_eps) {
   check_rows(a, "gemm: a");
   check_rows(w, "gemm: w");
   const GemmGeom g = gemm_geom(a, w, act, conv);
@@ -98,6 +98,10 @@ Tensor gemm_cuda(const Tensor& a, const Tensor& w, const optional<Tensor>& bias,
   p.a = bf(a); p.w = bf(w);
   p.lda = (int32_t)a.stride(0); p.ldw = (int32_t)w.stride(0);
   fill_gemm(p, a, g, out, bias, residual, row_bias, row_div, act, alpha, out_scale, out_f32, conv);
+  if (a_norm_eps >= 0.0) {                 // ABI 8: LayerNorm of the A rows as a prologue (affine part folded into w / bias)
+    p.a_norm = 1; p.a_norm_eps = (float)a_norm_eps;
+    TORCH_CHECK(tc_gemm_ws_eligible(&p) == 1, "gemm: a_norm_eps needs a problem the weight-stationary kernel takes");
+  }
   Tensor ws;
   const int64_t nbytes = tc_gemm_workspace(&p);
   if (nbytes > 0) {
@@ -150,7 +154,7 @@ Tensor gemm_mx_meta(const Tensor& aq, const Tensor&, const Tensor& wq, const Ten
 }
 
 Tensor gemm_meta(const Tensor& a, const Tensor& w, const optional<Tensor>&, const optional<Tensor>&, const optional<Tensor>&,
-                 int64_t, int64_t act, double, double, bool out_f32, at::IntArrayRef conv) {
+                 int64_t, int64_t act, double, double, bool out_f32, at::IntArrayRef conv, double) {
   const GemmGeom g = gemm_geom(a, w, act, conv);
   return at::empty({g.m, g.n_out}, a.options().dtype(out_f32 ? at::kFloat : at::kBFloat16));
 }
@@ -268,7 +272,7 @@ std::tuple<Tensor, Tensor> ddim_step_meta(const Tensor& x, const Tensor&, const 
 
 TORCH_LIBRARY(tooncrafter, m) {
   m.def("gemm(Tensor a, Tensor w, Tensor? bias, Tensor? residual, Tensor? row_bias, int row_div, int act, float alpha, "
-        "float out_scale, bool out_f32, int[] conv) -> Tensor");
+        "float out_scale, bool out_f32, int[] conv, float a_norm_eps=-1.0) -> Tensor");
   m.def("quant_mxfp8(Tensor x, int k) -> (Tensor, Tensor)");
   m.def("gemm_mx(Tensor aq, Tensor a_scale, Tensor wq, Tensor w_scale, Tensor? bias, Tensor? residual, Tensor? row_bias, "
         "int row_div, int act, float alpha, float out_scale, bool out_f32, int[] conv) -> Tensor");

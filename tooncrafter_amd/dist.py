@@ -50,6 +50,8 @@ def gather_clips(video: torch.Tensor, dst: int = 0, out: Optional[List[torch.Ten
     `shard_indices` spreading a remainder, ranks own different clip counts `b`: pass `ragged=True` and every rank
     is padded to the largest count (one extra all_gather of the counts), the padding cut off again on `dst`.
     Every rank must call this exactly once per step, also a rank that owns no clip (b = 0)."""
+    if ragged and out is not None:
+        raise ValueError("gather_clips(ragged=True) allocates its own padded buffers; `out=` is only for equal shards")
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [video]
     rank, world = dist.get_rank(), dist.get_world_size()

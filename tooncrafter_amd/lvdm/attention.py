@@ -23,7 +23,7 @@ import torch.nn as nn
 
 from .. import ops
 from .._lib import ACT_GEGLU
-from .common import Act, PackedModule, SourceKey, f32, pack_geglu, pack_linear
+from .common import Act, PackedModule, SourceKey, f32, fold_layernorm, pack_geglu, pack_linear
 
 
 class ContextCache:
@@ -102,9 +102,14 @@ class FeedForward(PackedModule):
         """(packed weight, gated) of the GEMM that reads the LayerNorm in front of this block."""
         return self.pk["w1"], True
 
-    def forward(self, x_norm, residual):
+    def forward(self, x_norm, residual, ln=None):
+        """`ln` = (folded packed weight, folded bias, eps): `x_norm` is then the RAW rows and the LayerNorm runs as the
+        prologue of the first GEMM (BasicTransformerBlock._pre)."""
         pk = self.pk
-        g = ops.gemm(x_norm, pk["w1"], pk["b1"], act=ACT_GEGLU)
+        if ln is not None:
+            g = ops.gemm(x_norm, ln[0], ln[1], act=ACT_GEGLU, a_norm_eps=ln[2])
+        else:
+            g = ops.gemm(x_norm, pk["w1"], pk["b1"], act=ACT_GEGLU)
         return ops.gemm(g, pk["w2"], pk["b2"], residual=residual)
 
 
@@ -149,18 +154,18 @@ class CrossAttention(PackedModule):
         return pk
 
     # -- self attention over the H*W tokens of each frame
-    def forward_spatial_self(self, x_norm, residual, act: Act):
+    def forward_spatial_self(self, x_norm, residual, act: Act, ln=None):
         pk = self.pk
         c = self.heads * 64
-        qkv = ops.gemm(x_norm, pk["wqkv"])
+        qkv = ops.gemm(x_norm, pk["wqkv"]) if ln is None else ops.gemm(x_norm, ln[0], ln[1], a_norm_eps=ln[2])
         a = ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], batch=act.frames, heads=self.heads,
                           lq=act.hw, lk=act.hw, scale=self.scale)
         return ops.gemm(a, pk["wo"], pk["bo"], residual=residual)
 
     # -- self attention over the T frames at each pixel
-    def forward_temporal_self(self, x_norm, residual, act: Act):
+    def forward_temporal_self(self, x_norm, residual, act: Act, ln=None):
         pk = self.pk
-        qkv = ops.gemm(x_norm, pk["wqkv"])
+        qkv = ops.gemm(x_norm, pk["wqkv"]) if ln is None else ops.gemm(x_norm, ln[0], ln[1], a_norm_eps=ln[2])
         a = ops.attention_temporal(qkv, b=act.b, t=act.t, hw=act.hw, heads=self.heads, scale=self.scale)
         return ops.gemm(a, pk["wo"], pk["bo"], residual=residual)
 
@@ -179,11 +184,11 @@ class CrossAttention(PackedModule):
             hit = ctx.kv[id(self)] = (self, kv_text, kv_img)
         return hit[1], hit[2]
 
-    def forward_cross(self, x_norm, residual, act: Act, ctx: ContextCache):
+    def forward_cross(self, x_norm, residual, act: Act, ctx: ContextCache, ln=None):
         pk = self.pk
         c = self.heads * 64
         kv_text, kv_img = self.context_kv(ctx)
-        q = ops.gemm(x_norm, pk["wq"])
+        q = ops.gemm(x_norm, pk["wq"]) if ln is None else ops.gemm(x_norm, ln[0], ln[1], a_norm_eps=ln[2])
         if kv_img is not None:
             if self.image_cross_attention_scale != 1.0:
                 raise NotImplementedError("image_cross_attention_scale != 1.0")
@@ -219,6 +224,8 @@ class BasicTransformerBlock(PackedModule):
         self.norm2 = nn.LayerNorm(dim)
         self.norm3 = nn.LayerNorm(dim)
 
+    LN_EPS = 1e-5
+
     def _pack(self):
         return {f"g{i}": f32(getattr(self, f"norm{i}").weight) for i in (1, 2, 3)} | \
                {f"b{i}": f32(getattr(self, f"norm{i}").bias) for i in (1, 2, 3)}
@@ -227,17 +234,52 @@ class BasicTransformerBlock(PackedModule):
         """`consumer`: the packed weight of the single linear GEMM that reads the normalised rows (fused qkv, GEGLU
         projection) -- lets the fp8 route have LayerNorm emit MXFP8 directly; ignored otherwise."""
         mx_for = None if consumer is None else (consumer.shape[0], consumer.shape[0] // 2 if gated else consumer.shape[0])
-        return ops.layernorm(x, self.pk[f"g{i}"], self.pk[f"b{i}"], 1e-5, mx_for=mx_for)
+        return ops.layernorm(x, self.pk[f"g{i}"], self.pk[f"b{i}"], self.LN_EPS, mx_for=mx_for)
+
+    def _folded(self, i, kind):
+        """Consumer weights of norm<i> with the LayerNorm's affine half folded in (common.fold_layernorm), packed like
+        the plain ones; built on first use, dropped with the rest of the packed tensors."""
+        pk = self.pk
+        key = f"ln{i}"
+        if key not in pk:
+            norm = getattr(self, f"norm{i}")
+            with torch.no_grad():
+                if kind == "ff":
+                    w, b = fold_layernorm(self.ff.net[0].proj.weight, self.ff.net[0].proj.bias, norm.weight, norm.bias)
+                    pk[key] = pack_geglu(w, b)
+                else:
+                    attn = self.attn1 if i == 1 else self.attn2
+                    raw = torch.cat([attn.to_q.weight, attn.to_k.weight, attn.to_v.weight], 0) if kind == "qkv" \
+                        else attn.to_q.weight
+                    w, b = fold_layernorm(raw, None, norm.weight, norm.bias)
+                    pk[key] = (pack_linear(w), b)
+        return (*pk[key], self.LN_EPS)
+
+    def _pre(self, x, i, consumer, kind):
+        """Input of the GEMM behind norm<i>: (LayerNorm(x), None), or -- when that GEMM can normalise its A rows itself
+        (K = 320 at level 0: ops.gemm_ln_eligible, the library's own rule) -- (x, folded consumer weights): the
+        LayerNorm launch and its HBM round trip (reference attention.py:242-246 runs it as its own kernel) disappear."""
+        gated = kind == "ff"
+        probe = getattr(ops.backend(), "gemm_ln_eligible", None)
+        if probe is not None and probe(x.shape[0], consumer.shape[0], consumer.shape[1], geglu=gated, lda=x.stride(0)):
+            return x, self._folded(i, kind)
+        return self._ln(x, i, consumer if kind != "q" else None, gated), None
 
     def forward_spatial(self, x, act: Act, ctx: ContextCache):
-        x = self.attn1.forward_spatial_self(self._ln(x, 1, self.attn1.pk["wqkv"]), x, act)
-        x = self.attn2.forward_cross(self._ln(x, 2), x, act, ctx)
-        return self.ff(self._ln(x, 3, *self.ff.ln_consumer()), x)
+        h, ln = self._pre(x, 1, self.attn1.pk["wqkv"], "qkv")
+        x = self.attn1.forward_spatial_self(h, x, act, ln=ln)
+        h, ln = self._pre(x, 2, self.attn2.pk["wq"], "q")
+        x = self.attn2.forward_cross(h, x, act, ctx, ln=ln)
+        h, ln = self._pre(x, 3, self.ff.pk["w1"], "ff")
+        return self.ff(h, x, ln=ln)
 
     def forward_temporal(self, x, act: Act):
-        x = self.attn1.forward_temporal_self(self._ln(x, 1, self.attn1.pk["wqkv"]), x, act)
-        x = self.attn2.forward_temporal_self(self._ln(x, 2, self.attn2.pk["wqkv"]), x, act)   # context=None -> self attention again
-        return self.ff(self._ln(x, 3, *self.ff.ln_consumer()), x)
+        h, ln = self._pre(x, 1, self.attn1.pk["wqkv"], "qkv")
+        x = self.attn1.forward_temporal_self(h, x, act, ln=ln)
+        h, ln = self._pre(x, 2, self.attn2.pk["wqkv"], "qkv")            # context=None -> self attention again
+        x = self.attn2.forward_temporal_self(h, x, act, ln=ln)
+        h, ln = self._pre(x, 3, self.ff.pk["w1"], "ff")
+        return self.ff(h, x, ln=ln)
 
 
 class SpatialTransformer(PackedModule):

@@ -277,7 +277,8 @@ class VideoDecoder(PackedModule):
         self.attn_refinement.append(Combiner(block_in))
         self.conv_out = AE3DConv(block_in, out_ch, video_kernel_size=video_kernel_size, kernel_size=3, stride=1, padding=1)
         self._ref_cache = None
-        self._graphs = {}          # (z shape, scale, with refs) -> static input/output + captured hipGraph
+        self._graphs = {}          # (z shape, scale, with refs, fp8 routing) -> static input/output + captured hipGraph
+        self._graph_epoch = PackedModule.graph_epoch()
         self.use_hipgraph = os.environ.get("TC_HIPGRAPH", "1") != "0"
 
     def _pack(self):
@@ -326,7 +327,13 @@ class VideoDecoder(PackedModule):
         ref = self.ref_cache(ref_context) if ref_context else None
         if not (self.use_hipgraph and z.is_cuda and probe is None and ops.backend().name == "hip"):
             return self._decode(z, ref, scale, probe)
-        key = (tuple(z.shape), float(scale), ref is not None)
+        be = ops.backend()
+        # the graph replays the kernels it recorded: the MXFP8 routing state is part of its identity, and so are the
+        # packed weight tensors (a load_state_dict / invalidate() since capture frees them: drop every graph then)
+        if self._graph_epoch != PackedModule.graph_epoch():
+            self._graphs.clear()
+            self._graph_epoch = PackedModule.graph_epoch()
+        key = (tuple(z.shape), float(scale), ref is not None, getattr(be, "fp8", None), getattr(be, "fp8_decoder", None))
         st = self._graphs.get(key)
         if st is None:
             st = self._graphs[key] = {"z": torch.empty(z.shape, dtype=torch.float32, device=z.device),

@@ -76,6 +76,17 @@ def pack_linear(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def fold_layernorm(w: torch.Tensor, b, gamma: torch.Tensor, beta: torch.Tensor):
+    """nn.Linear(LayerNorm(x)) = ((x - mean) * rstd) @ (w * gamma)^T + (b + w @ beta): the affine half of the LayerNorm
+    moved into the consumer's weight [N, K] and bias (fp32, exact in real arithmetic), so that the normalisation itself
+    can run as the prologue of that GEMM (ops.gemm(..., a_norm_eps=...), csrc/gemm_ws.hip).  -> (w', b') fp32."""
+    w = w.detach().reshape(w.shape[0], -1).to(torch.float32)
+    bias = w @ beta.detach().to(torch.float32)
+    if b is not None:
+        bias = bias + b.detach().to(torch.float32)
+    return w * gamma.detach().to(torch.float32)[None, :], bias.contiguous()
+
+
 def pack_conv3x3(w: torch.Tensor, cin_pad: int | None = None) -> torch.Tensor:
     """Conv2d [Co, Ci, 3, 3] -> bf16 [Co, 9 * Cip], K index = (ky*3 + kx) * Cip + ci."""
     w = w.detach()
@@ -119,6 +130,14 @@ class PackedModule(nn.Module):
     `load_state_dict(strict=True)` works with the reference's checkpoints) and a
     lazily built dict of packed device tensors used by forward."""
 
+    # Bumped whenever ANY module drops its packed tensors (new weights, new device): captured hipGraphs have the
+    # packed pointers baked in, so their owners compare this against the value at capture time (graph_epoch()).
+    _epoch = [0]
+
+    @staticmethod
+    def graph_epoch() -> int:
+        return PackedModule._epoch[0]
+
     def __init__(self):
         super().__init__()
         self._pk = None
@@ -134,14 +153,17 @@ class PackedModule(nn.Module):
         return self._pk
 
     def invalidate(self):
+        PackedModule._epoch[0] += 1
         for m in self.modules():
             if isinstance(m, PackedModule):
                 m._pk = None
 
     def _apply(self, fn, recurse=True):           # .cuda() / .to(): packed copies are stale
         self._pk = None
+        PackedModule._epoch[0] += 1
         return super()._apply(fn, recurse)
 
     def _load_from_state_dict(self, *a, **k):     # new weights: repack on next use
         self._pk = None
+        PackedModule._epoch[0] += 1
         return super()._load_from_state_dict(*a, **k)

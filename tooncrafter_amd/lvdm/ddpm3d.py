@@ -14,8 +14,9 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from .. import ops
 from ..utils import instantiate_from_config
-from .common import SourceKey
+from .common import PackedModule, SourceKey
 from .utils_diffusion import make_beta_schedule, rescale_zero_terminal_snr
 
 
@@ -254,11 +255,16 @@ class LatentDiffusion(DDPM):
             return unet(None, st["ts2"], context=st["ctx2"], fs=st["fs2"], x_parts=[st["x2"], st["cc2"]])
 
         if self.use_hipgraph and x_noisy.is_cuda:
+            # a captured graph replays the kernels and the packed-weight pointers it recorded: new weights
+            # (load_state_dict / invalidate) or another MXFP8 routing since capture make it stale
+            sig = (PackedModule.graph_epoch(), getattr(ops.backend(), "fp8", None))
+            if st["graph"] is not None and st.get("graph_sig") != sig:
+                st["graph"], st["calls"] = None, 0
             if st["graph"] is None and st["calls"] >= 1:             # first call ran eagerly (warm caches)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     st["out"] = fwd()
-                st["graph"] = g
+                st["graph"], st["graph_sig"] = g, sig
             if st["graph"] is not None:
                 st["graph"].replay()
                 out = st["out"]

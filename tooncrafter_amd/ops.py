@@ -96,6 +96,8 @@ class HipOps:
         self.fp8_fuse_ln = os.environ.get("TC_FP8_FUSE_LN", "1") != "0"     # LayerNorm emits MXFP8 for its fp8 consumer
         self.fp8_calls = {"mx": 0, "bf16": 0}
         self._wq = {}
+        # LayerNorm -> consumer GEMM fusion (ABI 8, gemm_ln_eligible); TC_FUSE_LN=0 keeps the separate launch (A/B runs)
+        self.fuse_ln = os.environ.get("TC_FUSE_LN", "1") != "0"
 
     # ------------------------------------------------------------------ workspace
     def _workspace(self, nbytes: int, device) -> torch.Tensor:
@@ -105,8 +107,12 @@ class HipOps:
     # ------------------------------------------------------------------ GEMM family
     def gemm(self, a, w, bias=None, *, act=ACT_NONE, residual=None, row_bias=None, row_div=0,
              alpha=1.0, out_scale=1.0, out=None, out_f32=False, conv=None, batch=1,
-             stride_a=0, stride_w=0, stride_c=0, m=None):
+             stride_a=0, stride_w=0, stride_c=0, m=None, a_norm_eps=None):
         """out[M, N'] = act(alpha * gather(a) @ w^T + bias + row_bias[m // row_div]) * out_scale + residual.
+
+        a_norm_eps (ABI 8): LayerNorm of the rows of `a` as a prologue of the product -- (x - mean) * rsqrt(var + eps)
+        over the K columns; gamma / beta must already be folded into w / bias (lvdm.common.fold_layernorm).  Only for
+        problems `gemm_ln_eligible` accepts (the weight-stationary K = 320 kernel).
 
         a: rows tensor (for conv modes the SOURCE rows, lda = a.stride(0));
         w: [N, K] bf16 contiguous; conv: None | dict(kind='3x3'|'t3', frames, t_len, h_in, w_in,
@@ -179,6 +185,12 @@ class HipOps:
         p.act, p.out_f32 = act, 1 if out_f32 else 0
         p.batch = batch
         p.stride_a, p.stride_w, p.stride_c = stride_a, stride_w, stride_c
+        if a_norm_eps is not None:
+            p.a_norm, p.a_norm_eps = 1, float(a_norm_eps)
+            if mx_a is not None or self.fp8 is not None and self._fp8_eligible(p, conv is not None, n_out, batch):
+                raise ValueError("gemm: a_norm_eps and the MXFP8 route exclude each other")
+            if not self.lib.tc_gemm_ws_eligible(C.byref(p)):
+                raise ValueError("gemm: a_norm_eps needs a problem the weight-stationary kernel takes (gemm_ln_eligible)")
         if self.fp8 is not None:
             if self._fp8_eligible(p, conv is not None, n_out, batch):
                 self.fp8_calls["mx"] += 1
@@ -193,6 +205,22 @@ class HipOps:
             p.workspace, p.workspace_bytes = ws.data_ptr(), nbytes
         _lib.check(self.lib.tc_gemm_bf16(C.byref(p), _stream()), "tc_gemm_bf16")
         return out
+
+    def gemm_ln_eligible(self, m, n, k, *, geglu=False, lda=None) -> bool:
+        """Would `gemm(a[m, k], w[n, k], act=GEGLU if geglu, a_norm_eps=...)` be accepted, i.e. may the caller drop the
+        LayerNorm launch in front of this projection?  ONE rule, the library's own (tc_gemm_ws_eligible); the MXFP8
+        route keeps its LayerNorm -> MXFP8 fusion instead."""
+        if not self.fuse_ln:
+            return False
+        p = TcGemmParams()
+        p.gather, p.m, p.n, p.k = GATHER_LINEAR, int(m), int(n), int(k)
+        p.lda, p.ldw = int(lda if lda is not None else k), int(k)
+        p.act = ACT_GEGLU if geglu else ACT_NONE
+        p.ldc = p.ldr = n // 2 if geglu else n
+        p.alpha, p.out_scale, p.batch = 1.0, 1.0, 1
+        if not self.lib.tc_gemm_ws_eligible(C.byref(p)):
+            return False
+        return not (self.fp8 is not None and self._fp8_eligible(p, False, p.ldc, 1))
 
     # ------------------------------------------------------------------ MXFP8 GEMM path (configs[4])
     def quant_mxfp8(self, x, k=None):
