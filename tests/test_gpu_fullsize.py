@@ -104,6 +104,25 @@ def test_ddim3_full_size_vs_oracle(full_model, golden, inp, fp8):
 
 
 @pytest.mark.timeout(1500)
+def test_decoder_full_size_two_clips_one_call(full_model, inp):
+    """BASELINE.json configs[3] (perframe_ae=False) at 320x512: two DIFFERENT clips through ONE decode_first_stage call
+    -- B * T = 32 frames per launch, level-0 activations of 2.7 GB, i.e. beyond what 31-bit tensor-relative buffer
+    offsets could address (the GEMM kernels address block-relatively, csrc/gemm_common.h) -- against the same clips
+    decoded one per call: bit for bit.  The reference raises on this call (lvdm/models/ddpm3d.py:656-657)."""
+    z1 = inp["z_dec"].to(DEV)
+    z2 = (torch.roll(z1, 3, dims=4) * 0.9).contiguous()
+    r1 = [r.to(DEV) for r in inp["refs"]]
+    r2 = [(torch.flip(r, dims=(-1,)) * 1.1).contiguous() for r in r1]
+    with torch.no_grad():
+        y1 = full_model.decode_first_stage(z1, ref_context=r1).clone()
+        y2 = full_model.decode_first_stage(z2, ref_context=r2).clone()
+        yy = full_model.decode_first_stage(torch.cat([z1, z2], 0), ref_context=[torch.cat([a, b], 0) for a, b in zip(r1, r2)])
+    assert tuple(yy.shape) == (2, 3, z1.shape[2], 320, 512) and torch.isfinite(yy).all()
+    assert not torch.equal(y1, y2)
+    assert torch.equal(yy[0], y1[0]) and torch.equal(yy[1], y2[0])
+
+
+@pytest.mark.timeout(1500)
 @pytest.mark.parametrize("tag", ["dec16", "dec14"])
 def test_decoder_full_size_vs_oracle(full_model, golden, inp, tag):
     """VideoDecoder at 40x64 latents -> 320x512: 16 frames, and the 14-frame re-decode that reuses the cached

@@ -70,7 +70,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams pin, co
   if (tile_m >= tiles_m) return;
 
   const int64_t bz = blockIdx.z;
-  const tc_rsrc_t a_rsrc = make_rsrc(reinterpret_cast<const bf16_t*>(p.a) + bz * p.stride_a, tc_a_extent(p));
   const tc_rsrc_t w_rsrc = make_rsrc(reinterpret_cast<const bf16_t*>(p.w) + bz * p.stride_w, tc_w_extent(p));
 
   // ---- loader geometry: thread -> (row lrow + 32 i, 16-byte chunk) of both tiles
@@ -82,6 +81,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams pin, co
   const int chunk = (tid & 7) ^ ((lrow >> 1) & 7);
   AGather<GATHER, RA> ag;
   ag.init(p, tile_m * BM, lrow, 32, chunk);
+  const tc_rsrc_t a_rsrc = tc_a_rsrc(p, bz, ag.row_lo);       // block-relative: 31-bit offsets span one tile's rows
   uint32_t b_voff[RB];
 #pragma unroll
   for (int i = 0; i < RB; ++i) {

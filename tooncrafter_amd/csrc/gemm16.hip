@@ -48,7 +48,6 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(const TcGemmParams p, co
   if (tile_m >= tiles_m) return;
 
   const int64_t bz = blockIdx.z;
-  const tc_rsrc_t a_rsrc = make_rsrc(reinterpret_cast<const bf16_t*>(p.a) + bz * p.stride_a, tc_a_extent(p));
   const tc_rsrc_t w_rsrc = make_rsrc(reinterpret_cast<const bf16_t*>(p.w) + bz * p.stride_w, tc_w_extent(p));
 
   // loader geometry as in gemm.hip: thread -> (row lrow + 32 i, 16-byte chunk); the swizzle (row>>1)&7 is
@@ -57,6 +56,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(const TcGemmParams p, co
   const int chunk = (tid & 7) ^ ((lrow >> 1) & 7);
   AGather<GATHER, T16_R> ag;
   ag.init(p, tile_m * T16_BM, lrow, 32, chunk);
+  const tc_rsrc_t a_rsrc = tc_a_rsrc(p, bz, ag.row_lo);       // block-relative: 31-bit offsets span one tile's rows
   uint32_t b_voff[T16_R];
 #pragma unroll
   for (int i = 0; i < T16_R; ++i) {

@@ -28,7 +28,11 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 //   not memory latency, was what held it at ~25 % of the MFMA roof;
 // * rows that do not exist (M/N tails, convolution zero padding, K tails) get voffset = TC_OOB, which
 //   is >= num_records, so the hardware returns zeros: no masking instructions at all.
-// Valid offsets must stay below 2 GiB (checked on the host).
+// Offsets are 31-bit, so the descriptor of the A operand does not start at the tensor but at the lowest source row the
+// BLOCK's tile can touch (tc_tile_row_lo: a 64-bit, block-uniform base folded into the SRD); per-lane offsets are
+// relative to that row.  A tile's rows span a few image rows (3x3), 2 frames + the tile (temporal taps) or the tile itself
+// (linear), so an activation of ANY size is addressable -- the batched decode of BASELINE configs[3] (2.7 GB per
+// level-0 tensor at two 320x512 clips) goes through one launch; the host checks the per-block span, not the tensor.
 // The descriptor's num_records is the TRUE byte extent of the operand (last row + its K columns), so a
 // mis-computed row / tap offset that leaves the operand reads zeros instead of whatever VA follows the
 // allocation (or faulting where nothing is mapped there); TC_OOB is >= any extent by construction.
@@ -121,10 +125,35 @@ inline int tc_gemm_tile_order(const TcGemmParams& p, int tiles_n) {
   return (chunk > 0 && tiles_n >= 2 * chunk && (int64_t)p.n * p.ldw * 2 > min_bytes) ? chunk : 0;
 }
 
+// Lowest source row of A that the tile whose first output row is `tile_row0` can touch (block-uniform; a lower bound).
+// Rows of one tile ascend in (frame, y, x), and so do their source rows, so the first row's top-left tap bounds them all.
+template <int GATHER>
+__device__ __forceinline__ int64_t tc_tile_row_lo(const TcGemmParams& p, int tile_row0) {
+  if (GATHER == TC_GATHER_LINEAR) return tile_row0;
+  if (GATHER == TC_GATHER_CONVT3) {
+    const int64_t r = (int64_t)tile_row0 - (int64_t)p.h_out * p.w_out;
+    return r > 0 ? r : 0;
+  }
+  const int q = tile_row0 / p.w_out;
+  const int f = q / p.h_out, y = q - f * p.h_out;
+  int iy = y * p.stride - p.pad;
+  if (iy < 0) iy = 0;
+  if (p.upsample) iy >>= 1;
+  const int64_t r = ((int64_t)f * p.h_in + iy) * p.w_in - 1;
+  return r > 0 ? r : 0;
+}
+
+// SRD of the A operand for one block: base = first byte of row `row_lo` of batch item bz, records = what is left of the
+// operand's true extent from there (clamped to the 31-bit range by make_rsrc)
+__device__ __forceinline__ tc_rsrc_t tc_a_rsrc(const TcGemmParams& p, int64_t bz, int64_t row_lo) {
+  return make_rsrc(reinterpret_cast<const bf16_t*>(p.a) + bz * p.stride_a + row_lo * p.lda, tc_a_extent(p) - row_lo * p.lda * 2);
+}
+
 // Per-thread gather state for `R` rows of the A tile.
 template <int GATHER, int R>
 struct AGather {
-  uint32_t base[R];    // byte offset of (row, chunk) -- the centre tap for convolutions; TC_OOB if row >= M
+  uint32_t base[R];    // byte offset of (row, chunk) from row_lo -- the centre tap for convolutions; TC_OOB if row >= M
+  int64_t row_lo;      // tc_tile_row_lo of this block: the row the SRD of A starts at
   uint32_t vbits[R];   // convolution: bit t set if tap t of this row is inside the image
   int f[R], y[R], x[R];  // generic 3x3 path (stride 2 / fused upsample) only
   bool ok[R];
@@ -135,6 +164,7 @@ struct AGather {
 
   __device__ __forceinline__ void init(const TcGemmParams& p, int tile_row0, int lrow, int row_step, int chunk) {
     const int hw = p.h_out * p.w_out;
+    row_lo = tc_tile_row_lo<GATHER>(p, tile_row0);
 #pragma unroll
     for (int i = 0; i < R; ++i) {
       const int mm = tile_row0 + lrow + row_step * i;
@@ -143,13 +173,14 @@ struct AGather {
       f[i] = y[i] = x[i] = 0;
       vbits[i] = ok[i] ? 0xffffffffu : 0u;
       if (GATHER == TC_GATHER_LINEAR) {
-        base[i] = ok[i] ? (uint32_t)((int64_t)mc * p.lda * 2 + chunk * 16) : TC_OOB;
+        base[i] = ok[i] ? (uint32_t)(((int64_t)mc - row_lo) * p.lda * 2 + chunk * 16) : TC_OOB;
       } else if (GATHER == TC_GATHER_CONV3x3) {
         const int q = mc / p.w_out;
         x[i] = mc - q * p.w_out;
         f[i] = q / p.h_out;
         y[i] = q - f[i] * p.h_out;
-        base[i] = (uint32_t)((((int64_t)f[i] * p.h_in + y[i]) * p.w_in + x[i]) * p.lda * 2 + chunk * 16);
+        // (rows past M take mc = 0, whose offset may wrap: every tap of theirs is masked by vbits / ok)
+        base[i] = (uint32_t)(((((int64_t)f[i] * p.h_in + y[i]) * p.w_in + x[i]) - row_lo) * p.lda * 2 + chunk * 16);
         uint32_t bits = 0;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -158,7 +189,7 @@ struct AGather {
         }
         vbits[i] = bits;
       } else {  // CONVT3
-        base[i] = (uint32_t)((int64_t)mc * p.lda * 2 + chunk * 16);
+        base[i] = (uint32_t)(((int64_t)mc - row_lo) * p.lda * 2 + chunk * 16);
         const int tt = (mc / hw) % p.t_len;
         vbits[i] = ok[i] ? ((tt > 0 ? 1u : 0u) | 2u | (tt + 1 < p.t_len ? 4u : 0u)) : 0u;
       }
@@ -190,7 +221,7 @@ struct AGather {
           const bool v = ok[i] && iy >= 0 && iy < hv && ix >= 0 && ix < wv;
           if (p.upsample) { iy >>= 1; ix >>= 1; }
           const int64_t src = ((int64_t)f[i] * p.h_in + iy) * p.w_in + ix;
-          voff[i] = v ? (uint32_t)(src * p.lda * 2 + chunk * 16) : TC_OOB;
+          voff[i] = v ? (uint32_t)((src - row_lo) * p.lda * 2 + chunk * 16) : TC_OOB;
         }
       }
     } else {  // CONVT3
@@ -203,10 +234,15 @@ struct AGather {
   }
 };
 
-// Host-side guard shared by the launchers: every byte offset a tile load can form must fit the
-// 31-bit range the out-of-range marker relies on.
+// Host-side guard shared by the launchers: every byte offset a tile load can form must fit the 31-bit range the
+// out-of-range marker relies on.  For A that is the span of ONE block's source rows from its tc_tile_row_lo (tiles of
+// at most 256 output rows), not the tensor.
 inline bool tc_gemm_offsets_fit(const TcGemmParams& p) {
-  const int64_t a_bytes = tc_a_rows(p) * p.lda * 2;
+  int64_t span_rows = 256;
+  if (p.gather == TC_GATHER_CONVT3) span_rows += 2 * (int64_t)p.h_out * p.w_out;
+  else if (p.gather == TC_GATHER_CONV3x3)
+    span_rows = ((int64_t)256 / (p.w_out > 0 ? p.w_out : 1) + 2) * p.stride * p.w_in + 4 * (int64_t)p.w_in + 8;
+  const int64_t a_bytes = (span_rows + 1) * p.lda * 2;
   const int64_t w_bytes = (int64_t)p.n * p.ldw * 2;
   return a_bytes < 0x7fffff00LL && w_bytes < 0x7fffff00LL;
 }

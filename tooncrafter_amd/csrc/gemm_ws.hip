@@ -285,7 +285,12 @@ static bool ws_shape_ok(const TcGemmParams& p, int batch, int mode) {
   if (!geglu && p.act != TC_ACT_NONE) return false;
   if (p.n % (geglu ? 256 : 320) != 0) return false;
   if (p.residual && geglu) return false;
-  if (mode == 1 && p.m < 8192) return false;        // below that the persistent blocks have < 1 tile per CU
+  // Heuristic (profiles/r03_ws_bench_hipblaslt_yardstick.txt, B = 2 shapes): the N = 320 projections are HBM-bound and gain
+  // 1.15x (plain / + residual) to 1.53x (LayerNorm prologue instead of a LayerNorm launch); with more than one N-slab the
+  // single wave per SIMD serialises LayerNorm, MFMAs and epilogue and the kernel LOSES to the tiled one (qkv 0.89x,
+  // 0.67x with the prologue; GEGLU 0.61x / 0.50x), and at M = 40960 it only ties -- so: one slab, plain, M >= 64K rows.
+  if (mode == 1 && (p.m < 65536 || geglu || p.n != 320)) return false;
+  if ((int64_t)p.m * p.lda * 2 >= 0x7fffff00LL) return false;       // this kernel addresses A from the tensor base
   if ((int64_t)p.m * p.ldc * 2 >= 0x7fffff00LL || (p.residual && (int64_t)p.m * p.ldr * 2 >= 0x7fffff00LL)) return false;
   return true;
 }

@@ -303,13 +303,11 @@ class LatentDiffusion(DDPM):
         ref_context = kwargs.get("ref_context")
         dec = self.first_stage_model.decoder
         scale = 1.0 / float(self.scale_factor)
-        # the kernels address an activation with 31-bit byte offsets: the largest one of a decode (level 0 input of the
-        # first block after the upsample: T * 8h * 8w rows x 2 ch channels bf16 = 1.34 GB per 16-frame 320x512 clip)
-        # bounds how many clips go through one call; more are decoded in groups (each group still has all T frames
-        # of its clips in ONE call, which is what the dual-reference fusion needs)
+        # B * T frames share every launch (BASELINE configs[3], the call the reference dies on at ddpm3d.py:656-657).
+        # The GEMM kernels address activations block-relatively (csrc/gemm_common.h: tc_tile_row_lo), so a tensor may
+        # exceed 2 GiB (level 0 of two 320x512 clips: 2.7 GB); what stays 32-bit is the ROW count of a launch.
         b, _, t, h, w = z.shape
-        per_clip = t * (8 * h) * (8 * w) * 2 * int(getattr(dec, "ch", 128)) * 2
-        bmax = max(1, int(0x7fffff00 // max(per_clip, 1)))
+        bmax = max(1, int(0x7fffffff // max(t * (8 * h) * (8 * w), 1)))
         if b <= bmax:
             return dec.decode_clip(z, ref_context, scale=scale)
         outs = []
