@@ -65,16 +65,18 @@ def linear_case(tag, m, n, k, geglu=False, res=False, ln=False, yard=True):
         x = hip.layernorm(a[i], g, be, 1e-5) if ln else a[i]
         hip.gemm(x, w, b, act=act, residual=r[i], out=out)
 
-    def ws(i):
-        env(1)
+    def ws(i, mode=2):
+        env(mode)
         if ln:
             hip.gemm(a[i], w, b, act=act, residual=r[i], out=out, a_norm_eps=1e-5)
         else:
             hip.gemm(a[i], w, b, act=act, residual=r[i], out=out)
 
     variants = {"tiled": tiled}
+    env(2)
     if k == 320 and hip.gemm_ln_eligible(m, n, k, geglu=geglu):
         variants["ws"] = ws
+        variants["ws deep store window"] = lambda i: ws(i, 4)
     if yard:
         wb = w32.to(BF)
 
@@ -92,7 +94,7 @@ def linear_case(tag, m, n, k, geglu=False, res=False, ln=False, yard=True):
     t = time_variants(variants)
     env(1)
     cells = "  |  ".join(f"{name} {med:8.1f} us (min {mn:7.1f}) {flop / med / 1e6:7.1f} TF/s" for name, (med, mn) in t.items())
-    extra = f"  x{t['tiled'][0] / t['ws'][0]:.2f}" if "ws" in t else ""
+    extra = f"  x{t['tiled'][0] / t['ws'][0]:.2f} / x{t['tiled'][0] / t['ws deep store window'][0]:.2f}" if "ws" in t else ""
     print(f"{tag:34s} {m}x{n}x{k}{' +LN' if ln else ''}{' +res' if res else ''}{' GEGLU' if geglu else ''}: {cells}{extra}", flush=True)
 
 

@@ -104,11 +104,18 @@ def test_ddim3_full_size_vs_oracle(full_model, golden, inp, fp8):
 
 
 @pytest.mark.timeout(1500)
-def test_decoder_full_size_two_clips_one_call(full_model, inp):
+def test_decoder_full_size_two_clips_one_call(full_model, golden, inp):
     """BASELINE.json configs[3] (perframe_ae=False) at 320x512: two DIFFERENT clips through ONE decode_first_stage call
-    -- B * T = 32 frames per launch, level-0 activations of 2.7 GB, i.e. beyond what 31-bit tensor-relative buffer
-    offsets could address (the GEMM kernels address block-relatively, csrc/gemm_common.h) -- against the same clips
-    decoded one per call: bit for bit.  The reference raises on this call (lvdm/models/ddpm3d.py:656-657)."""
+    -- B * T = 32 frames per launch, level-0 activations of 2.7 GB, beyond what 31-bit tensor-relative buffer offsets
+    could address (the GEMM kernels address block-relatively, csrc/gemm_common.h).  The reference raises on this call
+    (lvdm/models/ddpm3d.py:656-657).  Three statements:
+      * parity: clip 0 of the batched call against the fp32 oracle golden, under the single-clip bound;
+      * no cross-clip term: the same clip in both batch slots of one call gives bit-identical halves;
+      * against one-clip-per-call decodes: a 32-frame launch picks other tile families / split-K / GroupNorm chunkings
+        than a 16-frame one (the heuristics look at the row count), so this compares two bf16 REALISATIONS of the same
+        arithmetic -- each ~1.3e-2 from the fp32 oracle -- and must stay inside that scale (the addressing itself is pinned
+        bit for bit by test_gpu_ops.py::test_gemm_activation_beyond_2gib; the tiny decoder, whose launches keep their
+        geometry when batched, is bit-identical: test_gpu_models.py)."""
     z1 = inp["z_dec"].to(DEV)
     z2 = (torch.roll(z1, 3, dims=4) * 0.9).contiguous()
     r1 = [r.to(DEV) for r in inp["refs"]]
@@ -117,9 +124,19 @@ def test_decoder_full_size_two_clips_one_call(full_model, inp):
         y1 = full_model.decode_first_stage(z1, ref_context=r1).clone()
         y2 = full_model.decode_first_stage(z2, ref_context=r2).clone()
         yy = full_model.decode_first_stage(torch.cat([z1, z2], 0), ref_context=[torch.cat([a, b], 0) for a, b in zip(r1, r2)])
+        tw = full_model.decode_first_stage(torch.cat([z1, z1], 0), ref_context=[torch.cat([a, a], 0) for a in r1])
     assert tuple(yy.shape) == (2, 3, z1.shape[2], 320, 512) and torch.isfinite(yy).all()
     assert not torch.equal(y1, y2)
-    assert torch.equal(yy[0], y1[0]) and torch.equal(yy[1], y2[0])
+    flat = yy[0].reshape(-1)
+    got = flat[fc.sample_idx(flat.numel(), fc.N_OUT, 1).to(DEV)].cpu()
+    e_or = rel_l2(got, torch.from_numpy(golden["dec16_out"]))
+    e1, e2 = rel_l2(yy[0], y1[0]), rel_l2(yy[1], y2[0])
+    worst = float((yy[0] - y1[0]).abs().max())
+    print(f"two clips in one decode call: clip 0 vs fp32 oracle {e_or:.3e}; vs one clip per call rel-L2 {e1:.3e} / {e2:.3e} "
+          f"(max-abs {worst:.3e}); the clips themselves differ by {rel_l2(y1, y2):.3e}")
+    assert e_or <= DEC_REL
+    assert torch.equal(tw[0], tw[1])
+    assert e1 <= 2e-2 and e2 <= 2e-2 and worst < 0.5
 
 
 @pytest.mark.timeout(1500)

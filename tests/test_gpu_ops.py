@@ -152,6 +152,76 @@ def test_gemm_convt3(hip, emu, b, t, hw, c):
           emu.gemm(x, wt, bias, conv=geom, residual=res, out_scale=0.3), f"convt3 b{b} t{t} hw{hw} c{c}")
 
 
+@pytest.mark.parametrize("kind", ["linear", "3x3", "3x3s2", "3x3up", "t3"])
+def test_gemm_activation_beyond_2gib(hip, kind):
+    """An A operand larger than 2 GiB (BASELINE configs[3]: 32 frames of 320x512 through one launch).  Buffer offsets are
+    31-bit, so the kernels address A relative to the block's lowest source row (csrc/gemm_common.h: tc_tile_row_lo).
+    The rows of the UPPER half (the second 16-frame clip, past the 2 GiB mark) must equal, bit for bit, the same
+    launch over that half alone as its own (< 2 GiB) tensor: same tiles, same K order, only the addressing differs."""
+    frames, h, w, cin, cout = 32, 320, 512, 256, 64
+    if kind == "3x3up":
+        h, w = 160, 256
+        cin = 1024                                  # source 32 x 160 x 256 x 1024 bf16 = 2.7 GB, output 320 x 512
+    rows = frames * h * w
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.empty((rows, cin), dtype=BF16, device=DEV)
+    for i in range(0, rows, rows // 8):            # filled in pieces: randn of the whole tensor in fp32 would be 5-10 GB
+        x[i:i + rows // 8] = torch.randn((rows // 8, cin), generator=g, device=DEV).to(BF16)
+    assert x.numel() * 2 > 2 ** 31 + 2 ** 28
+    taps = {"linear": 1, "t3": 3}.get(kind, 9)
+    wt = rnd(cout, taps * cin, seed=6, scale=(taps * cin) ** -0.5)
+    bias = rnd(cout, seed=7, dtype=torch.float32)
+
+    def geom(fr):
+        if kind == "linear":
+            return None
+        if kind == "t3":
+            return dict(kind="t3", frames=fr, t_len=16, cin=cin, h_out=h, w_out=w)
+        stride, ups = (2, False) if kind == "3x3s2" else (1, kind == "3x3up")
+        ho = h * 2 if ups else (h - 1) // stride + 1
+        wo = w * 2 if ups else (w - 1) // stride + 1
+        return dict(kind="3x3", frames=fr, cin=cin, h_in=h, w_in=w, h_out=ho, w_out=wo, stride=stride, upsample=ups)
+    full = hip.gemm(x, wt, bias, conv=geom(frames))
+    half = hip.gemm(x[rows // 2:], wt, bias, conv=geom(frames // 2))
+    lo = hip.gemm(x[:rows // 2], wt, bias, conv=geom(frames // 2))
+    torch.cuda.synchronize()
+    n = full.shape[0] // 2
+    assert torch.isfinite(full).all() and float(full[n:].float().abs().mean()) > 0.1
+    assert torch.equal(full[:n], lo), f"{kind}: lower half differs"
+    assert torch.equal(full[n:], half), f"{kind}: rows past 2 GiB differ"
+
+
+@pytest.mark.parametrize("m,n,k,kind", [(4096, 320, 320, "linear"), (777, 1280, 64, "linear"), (2048, 640, 1984, "linear"),
+                                         (5120, 128, 128, "linear"), (2560, 320, 320, "3x3"), (1280, 1280, 640, "t3"),
+                                         (300, 96, 72, "linear")])
+def test_gemm_pipelined_loop_equals_plain_loop(hip, m, n, k, kind, monkeypatch):
+    """TC_GEMM_PIPE: two K-steps of LDS-DMA in flight (counted vmcnt, raw barriers) against the one-in-flight loop:
+    same tiles, same K order -> bit-identical, incl. 1-, 2- and odd-step K loops, K tails, residual / GEGLU epilogues."""
+    a_rows = m
+    if kind == "3x3":
+        geom = dict(kind="3x3", frames=1, cin=k, h_in=40, w_in=64, h_out=40, w_out=64, stride=1, upsample=False)
+        kk = 9 * k
+    elif kind == "t3":
+        geom = dict(kind="t3", frames=8, t_len=4, cin=k, h_out=10, w_out=16)
+        kk = 3 * k
+    else:
+        geom, kk = None, k
+    a, w = rnd(a_rows, k, seed=31), rnd(n, kk, seed=32, scale=kk ** -0.5)
+    bias, res = rnd(n, seed=33, dtype=torch.float32), rnd(m, n, seed=34)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("TC_GEMM_PIPE", mode)
+        monkeypatch.setenv("TC_GEMM_TILE16", "0")
+        monkeypatch.setenv("TC_GEMM_WS", "0")
+        o = [hip.gemm(a, w, bias, conv=geom, residual=res), hip.gemm(a, w, None, conv=geom, act=ACT_SILU, out_scale=0.5)]
+        if n % 128 == 0 and geom is None:
+            o.append(hip.gemm(a, w, bias, act=ACT_GEGLU))
+        torch.cuda.synchronize()
+        outs[mode] = o
+    for x, y in zip(outs["0"], outs["1"]):
+        assert torch.isfinite(x).all() and torch.equal(x, y)
+
+
 def test_gemm_batched(hip, emu):
     f, l, c = 3, 200, 128
     q, k = rnd(f * l, c, seed=24), rnd(f * l, c, seed=25)

@@ -37,8 +37,18 @@ constexpr int BK = TC_BK;
 // low-resolution layers whose 128-tiles would not fill the 256 CUs; the big-M layers go to the
 // 256-row kernel of gemm_wide.hip.
 
-template <int GATHER, int TM, int TN>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams pin, const int splits, const int order) {
+// PIPE: the K loop keeps TWO K-steps of tile loads in flight (both LDS stages requested before the first wait, stage k
+// re-requested as soon as every wave has consumed it) with counted s_waitcnt vmcnt + raw s_barrier -- a __syncthreads()
+// would drain the LDS-DMA queue (cdna_hip_programming.md, "Pipelining across barriers").  The plain loop has ONE K-step
+// in flight behind vmcnt(0) + barrier: with K = 320-1280 a tile's life is mostly exposed load latency.
+template <int N>
+__device__ __forceinline__ void gemm_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int GATHER, int TM, int TN, bool PIPE>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams pin, const int splits, const int order,
+                                                      const int late_epi) {
   // split-K (blockIdx.y = slice of the K loop): the block emits its raw fp32 partial tile into the
   // workspace -- the plain epilogue with every fused term switched off -- and splitk_reduce_kernel
   // finishes the job
@@ -166,12 +176,46 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams pin, co
   const int per = (nk_all + splits - 1) / splits;
   const int kb0 = blockIdx.y * per;
   const int nk = min(nk_all, kb0 + per);          // this block runs K-steps [kb0, nk); possibly none
-  if (kb0 < nk) {
+  // epilogue operands from global memory are requested early (gemm_epilogue.h: EpiPrefetch): the bias here, the
+  // residual rows in front of the last K-step -- both land under the MFMAs
+  const int n_out = p.act == TC_ACT_GEGLU ? p.n / 2 : p.n;
+  const bool fast_epi = (n_out & 7) == 0;
+  const bool geglu = TN == 2 && p.act == TC_ACT_GEGLU;
+  EpiPrefetch pre;
+  pre.have_res = false;
+  const bool early = fast_epi && !late_epi;        // late_epi (TC_GEMM_EPI_LATE=1, A/B runs): everything inside the epilogue
+  if (early) {
+    if (geglu) epi_load_bias<true, BM, BN>(p, tid, tile_n, pre);
+    else epi_load_bias<false, BM, BN>(p, tid, tile_n, pre);
+  }
+  if (PIPE) {
+    if (kb0 < nk) {
+      load_tile(kb0, 0);
+      if (kb0 + 1 < nk) load_tile(kb0 + 1, 1);
+      for (int kb = kb0; kb < nk; ++kb) {
+        const int st = (kb - kb0) & 1;
+        // stage st has landed: this wave's pieces (the RA + RB requests of the other stage may stay in flight), then
+        // everybody's (barrier)
+        if (kb + 1 < nk) gemm_wait_vmcnt<RA + RB>();
+        else gemm_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kb + 1 == nk && early && !geglu && p.residual) epi_load_residual<BM, BN>(p, tid, tile_m, tile_n, bz, pre);
+        compute(st);
+        if (kb + 2 < nk) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();          // every wave is done reading stage st (its fragments are in registers)
+          load_tile(kb + 2, st);
+        }
+      }
+      __syncthreads();                           // the epilogue reuses the stage buffers
+    }
+  } else if (kb0 < nk) {
     load_tile(kb0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kb = kb0; kb < nk; ++kb) {
       if (kb + 1 < nk) load_tile(kb + 1, (kb + 1 - kb0) & 1);
+      else if (early && !geglu && p.residual) epi_load_residual<BM, BN>(p, tid, tile_m, tile_n, bz, pre);
       compute((kb - kb0) & 1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -192,15 +236,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams pin, co
       }
   __syncthreads();
 
-  const int n_out = p.act == TC_ACT_GEGLU ? p.n / 2 : p.n;
-  if ((n_out & 7) != 0) epilogue_tail<BM, BN>(p, cs, tid, tile_m, tile_n, bz);
-  else if (TN == 2 && p.act == TC_ACT_GEGLU) {
-    if (p.alpha == 1.f && p.out_scale == 1.f) epilogue_fast<true, BM, BN, true>(p, cs, tid, tile_m, tile_n, bz);
-    else epilogue_fast<true, BM, BN, false>(p, cs, tid, tile_m, tile_n, bz);
+  if (fast_epi && !early) {
+    if (geglu) epi_load_bias<true, BM, BN>(p, tid, tile_n, pre);
+    else epi_load_bias<false, BM, BN>(p, tid, tile_n, pre);
+  }
+  if (!fast_epi) epilogue_tail<BM, BN>(p, cs, tid, tile_m, tile_n, bz);
+  else if (geglu) {
+    if (p.alpha == 1.f && p.out_scale == 1.f) epilogue_fast<true, BM, BN, true>(p, cs, tid, tile_m, tile_n, bz, pre);
+    else epilogue_fast<true, BM, BN, false>(p, cs, tid, tile_m, tile_n, bz, pre);
   }
   else if (p.alpha == 1.f && p.out_scale == 1.f && p.act == TC_ACT_NONE && !p.row_bias)
-    epilogue_fast<false, BM, BN, true>(p, cs, tid, tile_m, tile_n, bz);
-  else epilogue_fast<false, BM, BN, false>(p, cs, tid, tile_m, tile_n, bz);
+    epilogue_fast<false, BM, BN, true>(p, cs, tid, tile_m, tile_n, bz, pre);
+  else epilogue_fast<false, BM, BN, false>(p, cs, tid, tile_m, tile_n, bz, pre);
 }
 
 // Sum the split-K partial tiles (fixed order: bit-reproducible) and apply the epilogue of `p`:
@@ -363,12 +410,20 @@ extern "C" int tc_gemm_bf16(const TcGemmParams* pp, void* stream) {
   if (nblk > 0x7fffffffLL || batch > 65535) return TC_ESHAPE;
   dim3 grid((unsigned)nblk, (unsigned)splits, (unsigned)batch), block(256);
   const int order = nmajor ? -1 : tc_gemm_tile_order(p, tiles_n);
+  // TC_GEMM_PIPE = 0: the one-K-step-in-flight loop; 1 (default): two in flight (read per call: A/B in one process)
+  const bool pipe = [] { const char* e = getenv("TC_GEMM_PIPE"); return !(e && e[0] == '0'); }();
+  const int late_epi = [] { const char* e = getenv("TC_GEMM_EPI_LATE"); return (e && e[0] == '1') ? 1 : 0; }();
+#define TC_LAUNCH_GEMM_P(G, P)                                                                      \
+  do {                                                                                              \
+    if (tm == 2 && tn == 2) hipLaunchKernelGGL((gemm_kernel<G, 2, 2, P>), grid, block, 0, s, p, splits, order, late_epi);   \
+    else if (tm == 2) hipLaunchKernelGGL((gemm_kernel<G, 2, 1, P>), grid, block, 0, s, p, splits, order, late_epi);         \
+    else if (tn == 2) hipLaunchKernelGGL((gemm_kernel<G, 1, 2, P>), grid, block, 0, s, p, splits, order, late_epi);         \
+    else hipLaunchKernelGGL((gemm_kernel<G, 1, 1, P>), grid, block, 0, s, p, splits, order, late_epi);                      \
+  } while (0)
 #define TC_LAUNCH_GEMM(G)                                                                           \
   do {                                                                                              \
-    if (tm == 2 && tn == 2) hipLaunchKernelGGL((gemm_kernel<G, 2, 2>), grid, block, 0, s, p, splits, order);      \
-    else if (tm == 2) hipLaunchKernelGGL((gemm_kernel<G, 2, 1>), grid, block, 0, s, p, splits, order);            \
-    else if (tn == 2) hipLaunchKernelGGL((gemm_kernel<G, 1, 2>), grid, block, 0, s, p, splits, order);            \
-    else hipLaunchKernelGGL((gemm_kernel<G, 1, 1>), grid, block, 0, s, p, splits, order);                         \
+    if (pipe) TC_LAUNCH_GEMM_P(G, true);                                                            \
+    else TC_LAUNCH_GEMM_P(G, false);                                                                \
   } while (0)
   switch (p.gather) {
     case TC_GATHER_LINEAR: TC_LAUNCH_GEMM(TC_GATHER_LINEAR); break;
@@ -376,6 +431,7 @@ extern "C" int tc_gemm_bf16(const TcGemmParams* pp, void* stream) {
     default: TC_LAUNCH_GEMM(TC_GATHER_CONVT3); break;
   }
 #undef TC_LAUNCH_GEMM
+#undef TC_LAUNCH_GEMM_P
   TC_LAUNCH_CHECK();
   if (splits > 1) {
     const int64_t vecs = (int64_t)p.m * (p.n >> 3);

@@ -31,7 +31,8 @@ constexpr int T16_WT = 80;                                   // wave tile
 constexpr int T16_NT = T16_WT / 16;                          // 5 MFMA tiles per wave-tile side
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-template <int GATHER>
+// PIPE: two K-steps of tile loads in flight, counted vmcnt + raw barriers (see gemm.hip)
+template <int GATHER, bool PIPE>
 __global__ __launch_bounds__(256, 2) void gemm16_kernel(const TcGemmParams p, const int order) {
   __shared__ __attribute__((aligned(1024))) char smem[2 * T16_STAGE];
 
@@ -118,14 +119,32 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(const TcGemmParams p, co
   };
 
   const int nk = (p.k + TC_BK - 1) / TC_BK;
-  load_tile(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int kb = 0; kb < nk; ++kb) {
-    if (kb + 1 < nk) load_tile(kb + 1, (kb + 1) & 1);
-    compute(kb & 1);
+  if (PIPE) {
+    load_tile(0, 0);
+    if (nk > 1) load_tile(1, 1);
+    for (int kb = 0; kb < nk; ++kb) {
+      // stage kb & 1 has landed (the 2 * T16_R requests of the other stage may stay in flight), for every wave
+      if (kb + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * T16_R) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      compute(kb & 1);
+      if (kb + 2 < nk) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();            // every wave has its fragments of this stage in registers
+        load_tile(kb + 2, kb & 1);
+      }
+    }
+    __syncthreads();                             // the epilogue slabs reuse the stage buffers
+  } else {
+    load_tile(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    for (int kb = 0; kb < nk; ++kb) {
+      if (kb + 1 < nk) load_tile(kb + 1, (kb + 1) & 1);
+      compute(kb & 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: per wave, five passes of one 16-row tile row through a private fp32 slab [16][80]
@@ -225,10 +244,17 @@ int tc_gemm_tile16_try(const TcGemmParams& p, int batch, hipStream_t s) {
   if (nblk > 0x7fffffffLL) return 0;
   dim3 grid((unsigned)nblk, 1, (unsigned)batch), block(256);
   const int order = tc_gemm_tile_order(p, tiles_n);
+  const bool pipe = [] { const char* e = getenv("TC_GEMM_PIPE"); return !(e && e[0] == '0'); }();   // per call (A/B runs)
+#define TC_LAUNCH16(G)                                                                              \
+  do {                                                                                              \
+    if (pipe) hipLaunchKernelGGL((gemm16_kernel<G, true>), grid, block, 0, s, p, order);            \
+    else hipLaunchKernelGGL((gemm16_kernel<G, false>), grid, block, 0, s, p, order);                \
+  } while (0)
   switch (p.gather) {
-    case TC_GATHER_LINEAR: hipLaunchKernelGGL((gemm16_kernel<TC_GATHER_LINEAR>), grid, block, 0, s, p, order); break;
-    case TC_GATHER_CONV3x3: hipLaunchKernelGGL((gemm16_kernel<TC_GATHER_CONV3x3>), grid, block, 0, s, p, order); break;
-    default: hipLaunchKernelGGL((gemm16_kernel<TC_GATHER_CONVT3>), grid, block, 0, s, p, order); break;
+    case TC_GATHER_LINEAR: TC_LAUNCH16(TC_GATHER_LINEAR); break;
+    case TC_GATHER_CONV3x3: TC_LAUNCH16(TC_GATHER_CONV3x3); break;
+    default: TC_LAUNCH16(TC_GATHER_CONVT3); break;
   }
+#undef TC_LAUNCH16
   return 1;
 }

@@ -23,7 +23,8 @@ namespace {
 constexpr int WBM = 256;
 constexpr int WTHREADS = 512;
 
-template <int GATHER, int TNW>
+// PIPE: two K-steps of tile loads in flight, counted vmcnt + raw barriers (see gemm.hip)
+template <int GATHER, int TNW, bool PIPE>
 __global__ __launch_bounds__(WTHREADS, 2) void gemm_wide_kernel(const TcGemmParams p, const int order) {
   constexpr int BN = 64 * TNW;
   constexpr int WN = 32 * TNW;                         // columns per wave
@@ -139,14 +140,31 @@ __global__ __launch_bounds__(WTHREADS, 2) void gemm_wide_kernel(const TcGemmPara
   // LDS-DMA data is visible to a ds_read only after the issuing wave's vmcnt wait AND a barrier the
   // reader has passed; the same barrier retires the reads of the stage the next iteration overwrites.
   const int nk = (p.k + TC_BK - 1) / TC_BK;
-  load_tile(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int kb = 0; kb < nk; ++kb) {
-    if (kb + 1 < nk) load_tile(kb + 1, (kb + 1) & 1);
-    compute(kb & 1);
+  if (PIPE) {
+    load_tile(0, 0);
+    if (nk > 1) load_tile(1, 1);
+    for (int kb = 0; kb < nk; ++kb) {
+      if (kb + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RA + RB) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      compute(kb & 1);
+      if (kb + 2 < nk) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();            // every wave has its fragments of this stage in registers
+        load_tile(kb + 2, kb & 1);
+      }
+    }
+    __syncthreads();                             // the epilogue slabs reuse the stage buffers
+  } else {
+    load_tile(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    for (int kb = 0; kb < nk; ++kb) {
+      if (kb + 1 < nk) load_tile(kb + 1, (kb + 1) & 1);
+      compute(kb & 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: per wave, 4 passes of 16 rows through a private fp32 slab
@@ -268,11 +286,18 @@ template <int TNW>
 void launch_wide(const TcGemmParams& p, dim3 grid, hipStream_t s) {
   dim3 block(WTHREADS);
   const int order = tc_gemm_tile_order(p, (p.n + 64 * TNW - 1) / (64 * TNW));
+  const bool pipe = [] { const char* e = getenv("TC_GEMM_PIPE"); return !(e && e[0] == '0'); }();   // per call (A/B runs)
+#define TC_LAUNCH_WIDE(G)                                                                           \
+  do {                                                                                              \
+    if (pipe) hipLaunchKernelGGL((gemm_wide_kernel<G, TNW, true>), grid, block, 0, s, p, order);    \
+    else hipLaunchKernelGGL((gemm_wide_kernel<G, TNW, false>), grid, block, 0, s, p, order);        \
+  } while (0)
   switch (p.gather) {
-    case TC_GATHER_LINEAR: hipLaunchKernelGGL((gemm_wide_kernel<TC_GATHER_LINEAR, TNW>), grid, block, 0, s, p, order); break;
-    case TC_GATHER_CONV3x3: hipLaunchKernelGGL((gemm_wide_kernel<TC_GATHER_CONV3x3, TNW>), grid, block, 0, s, p, order); break;
-    default: hipLaunchKernelGGL((gemm_wide_kernel<TC_GATHER_CONVT3, TNW>), grid, block, 0, s, p, order); break;
+    case TC_GATHER_LINEAR: TC_LAUNCH_WIDE(TC_GATHER_LINEAR); break;
+    case TC_GATHER_CONV3x3: TC_LAUNCH_WIDE(TC_GATHER_CONV3x3); break;
+    default: TC_LAUNCH_WIDE(TC_GATHER_CONVT3); break;
   }
+#undef TC_LAUNCH_WIDE
 }
 
 int wide_enabled() {

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_kernel(const TcGemmParams p, c
   constexpr int EPI_IT = (16 * VPR + 63) / 64;       // store instructions per 16-row pass
   constexpr int STORES = WS_MT * EPI_IT;             // per wave per tile (issued unconditionally: static count)
   constexpr int SLAB_FLOATS = 16 * OCOLS;
-  static_assert(WS_LOADS + 2 * STORES <= 63, "vmcnt is 6 bits");
+  static_assert(WS_LOADS + (RES ? 4 : 2) * STORES <= 63, "vmcnt is 6 bits");
   __shared__ __attribute__((aligned(1024))) char smem[WS_STAGES * WS_TILE_BYTES + 4 * SLAB_FLOATS * 4];
 
   const int tid = threadIdx.x;
@@ -148,8 +148,13 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_kernel(const TcGemmParams p, c
     // ---- tile t has landed (this wave's pieces), then every wave's (barrier).  Operations issued after its DMA:
     // t = 0: the DMA of tile 1; t >= 1: the previous iteration's DMA of tile t+1, residual loads and stores
     // (vmcnt retires in issue order; waiting for a smaller count than necessary is always safe)
-    if (safe_wait) wait_vmcnt<0>();
+    // Counting: the operations issued after the DMA of tile t are [residual loads (t-2), stores (t-2), DMA (t+1),
+    // residual loads (t-1), stores (t-1)].  The default count lets the newest LOADS + (2 | 1) * STORES of them stay in
+    // flight -- which also retires the stores of iteration t-2; safe_wait = 2 keeps those in flight as well (their
+    // write acknowledgements can take longer than one ~1.5 us iteration: measured by scripts/ws_bench.py).
+    if (safe_wait == 1) wait_vmcnt<0>();
     else if (t == 0) wait_vmcnt<WS_LOADS>();
+    else if (safe_wait == 2 && t > 1) wait_vmcnt<WS_LOADS + (RES ? 4 : 2) * STORES>();
     else wait_vmcnt<WS_LOADS + (RES ? 2 : 1) * STORES>();
     __builtin_amdgcn_s_barrier();
     // the barrier also says: every wave is done reading stage (t + 2) % 3 (tile t - 1): refill it
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_kernel(const TcGemmParams p, c
   wait_vmcnt<0>();        // the two run-ahead DMA requests target this block's LDS: drain them before it is released
 }
 
-int ws_mode() {            // TC_GEMM_WS = 0 never | 1 heuristic (default) | 2 whenever the shape allows | 3 = 2 + vmcnt(0) waits
+int ws_mode() {            // TC_GEMM_WS = 0 never | 1 heuristic (default) | 2 whenever the shape allows | 3 = 2 + vmcnt(0) waits | 4 = 2 + deeper store window | 5 = 1 + deeper store window
   const char* e = getenv("TC_GEMM_WS");      // read per call: the parity tests flip it inside one process
   return e ? atoi(e) : 1;
 }
@@ -289,7 +294,7 @@ static bool ws_shape_ok(const TcGemmParams& p, int batch, int mode) {
   // 1.15x (plain / + residual) to 1.53x (LayerNorm prologue instead of a LayerNorm launch); with more than one N-slab the
   // single wave per SIMD serialises LayerNorm, MFMAs and epilogue and the kernel LOSES to the tiled one (qkv 0.89x,
   // 0.67x with the prologue; GEGLU 0.61x / 0.50x), and at M = 40960 it only ties -- so: one slab, plain, M >= 64K rows.
-  if (mode == 1 && (p.m < 65536 || geglu || p.n != 320)) return false;
+  if ((mode == 1 || mode == 5) && (p.m < 65536 || geglu || p.n != 320)) return false;
   if ((int64_t)p.m * p.lda * 2 >= 0x7fffff00LL) return false;       // this kernel addresses A from the tensor base
   if ((int64_t)p.m * p.ldc * 2 >= 0x7fffff00LL || (p.residual && (int64_t)p.m * p.ldr * 2 >= 0x7fffff00LL)) return false;
   return true;
@@ -311,7 +316,7 @@ int tc_gemm_ws_try(const TcGemmParams& p, int batch, hipStream_t s) {
   if (nchunks < 1) nchunks = 1;
   if (nchunks > ntiles) nchunks = ntiles;
   const int grid = slabs * 8 * ((nchunks + 7) / 8);
-  const int safe = mode == 3 ? 1 : 0;
+  const int safe = mode == 3 ? 1 : (mode >= 4 ? 2 : 0);
   const bool res = p.residual != nullptr, ln = p.a_norm != 0;
   dim3 g((unsigned)grid), b(256);
 #define TC_WS_LAUNCH(NT, G, R, L) hipLaunchKernelGGL((gemm_ws_kernel<NT, G, R, L>), g, b, 0, s, p, nchunks, safe)
