@@ -58,7 +58,7 @@ def case(tag, m, n, k, geglu=False, res=False, conv=None, a_rows=None, extra_env
     os.environ["TC_GEMM_WS"] = "0"
     for key, val in (extra_env or {}).items():
         os.environ[key] = val
-    t = time_variants({"r02": lambda i: run(i, "0", "1"), "plain": lambda i: run(i, "0"), "pipelined": lambda i: run(i, "1")})
+    t = time_variants({"r02": lambda i: run(i, "0", "1"), "plain": lambda i: run(i, "0"), "pipelined": lambda i: run(i, "2")})
     for key in (extra_env or {}):
         os.environ.pop(key)
     fl = 2.0 * m * n * kk

@@ -244,7 +244,9 @@ int tc_gemm_tile16_try(const TcGemmParams& p, int batch, hipStream_t s) {
   if (nblk > 0x7fffffffLL) return 0;
   dim3 grid((unsigned)nblk, 1, (unsigned)batch), block(256);
   const int order = tc_gemm_tile_order(p, tiles_n);
-  const bool pipe = [] { const char* e = getenv("TC_GEMM_PIPE"); return !(e && e[0] == '0'); }();   // per call (A/B runs)
+  // TC_GEMM_PIPE = 2 only: on this tile the deeper prefetch measured 0.97-1.02x (profiles/r03_pipe_bench.txt) -- two
+  // blocks of 80 KiB per CU already overlap each other's load latency -- so the default keeps the plain loop
+  const bool pipe = [] { const char* e = getenv("TC_GEMM_PIPE"); return e && e[0] == '2'; }();      // per call (A/B runs)
 #define TC_LAUNCH16(G)                                                                              \
   do {                                                                                              \
     if (pipe) hipLaunchKernelGGL((gemm16_kernel<G, true>), grid, block, 0, s, p, order);            \

@@ -286,7 +286,10 @@ template <int TNW>
 void launch_wide(const TcGemmParams& p, dim3 grid, hipStream_t s) {
   dim3 block(WTHREADS);
   const int order = tc_gemm_tile_order(p, (p.n + 64 * TNW - 1) / (64 * TNW));
-  const bool pipe = [] { const char* e = getenv("TC_GEMM_PIPE"); return !(e && e[0] == '0'); }();   // per call (A/B runs)
+  // TC_GEMM_PIPE = 2 only: with one 8-wave block per CU the second barrier per K-step costs more than the deeper
+  // prefetch returns (measured, profiles/r03_pipe_bench.txt: the decoder's 512-channel convolutions 0.91x, the
+  // N = 10240 GEGLU layer 0.95x), so the default keeps the plain loop
+  const bool pipe = [] { const char* e = getenv("TC_GEMM_PIPE"); return e && e[0] == '2'; }();      // per call (A/B runs)
 #define TC_LAUNCH_WIDE(G)                                                                           \
   do {                                                                                              \
     if (pipe) hipLaunchKernelGGL((gemm_wide_kernel<G, TNW, true>), grid, block, 0, s, p, order);    \
