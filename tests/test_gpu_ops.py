@@ -222,23 +222,6 @@ def test_gemm_pipelined_loop_equals_plain_loop(hip, m, n, k, kind, monkeypatch):
         assert torch.isfinite(x).all() and torch.equal(x, y)
 
 
-@pytest.mark.parametrize("batch,heads,lq,lk,kv_bdiv,lk2", [(2, 2, 200, 130, 1, 0), (4, 1, 64, 64, 2, 0), (3, 2, 300, 1, 1, 0),
-                                                          (2, 3, 129, 257, 1, 16), (2, 5, 640, 77, 2, 300)])
-def test_attention_ring_of_three_equals_two_stages(hip, batch, heads, lq, lk, kv_bdiv, lk2, monkeypatch):
-    """TC_ATTN_RING=3 (two K/V tiles of LDS-DMA in flight) computes the same sums in the same order as the two-stage
-    loop: bit-identical, incl. one-tile, ragged and dual (text + image) streams."""
-    hd = heads * 64
-    kvb = (batch + kv_bdiv - 1) // kv_bdiv
-    q, k, v = rnd(batch * lq, hd, seed=41), rnd(kvb * lk, hd, seed=42), rnd(kvb * lk, hd, seed=43)
-    kw = dict(k2=rnd(batch * lk2, hd, seed=44), v2=rnd(batch * lk2, hd, seed=45), lk2=lk2, kv2_bdiv=1) if lk2 else {}
-    outs = []
-    for mode in ("2", "3"):
-        monkeypatch.setenv("TC_ATTN_RING", mode)
-        outs.append(hip.attention(q, k, v, batch=batch, heads=heads, lq=lq, lk=lk, kv_bdiv=kv_bdiv, **kw))
-        torch.cuda.synchronize()
-    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
-
-
 def test_gemm_batched(hip, emu):
     f, l, c = 3, 200, 128
     q, k = rnd(f * l, c, seed=24), rnd(f * l, c, seed=25)

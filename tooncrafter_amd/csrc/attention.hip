@@ -227,12 +227,12 @@ __device__ __forceinline__ u32x2 lds_read_tr16_b64(const char* p) {
   return __builtin_bit_cast(u32x2, v);
 }
 
-// RING3: three-stage K/V ring with TWO tiles of LDS-DMA in flight (counted vmcnt + raw barrier, one barrier per tile:
-// the stage refilled in iteration kt is the one read in iteration kt - 1) instead of two stages with one tile in flight
-// behind vmcnt(0) + __syncthreads(): 48 KiB instead of 32 KiB of LDS per block (three resident blocks instead of four).
-template <bool DUAL, bool RING3>
+// (A three-stage K/V ring with two tiles of LDS-DMA in flight -- counted vmcnt, raw barrier, 48 KiB -- was built, bit-identical,
+// and measured 0.95-1.00x on every shape, profiles/r03_attn_ring_of_three_ab.txt: four resident blocks per CU already
+// hide the tile latency and the third stage costs one of them.  Removed.)
+template <bool DUAL>
 __global__ __launch_bounds__(256) void attn_d64_dma_kernel(const TcAttnParams p) {
-  __shared__ __attribute__((aligned(1024))) char smem[(RING3 ? 3 : 2) * DMA_STAGE];
+  __shared__ __attribute__((aligned(1024))) char smem[2 * DMA_STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -306,27 +306,14 @@ __global__ __launch_bounds__(256) void attn_d64_dma_kernel(const TcAttnParams p)
 
     const int n_tiles = (lk + KT - 1) / KT;
     dma_tile(0, 0);
-    if (RING3 && n_tiles > 1) dma_tile(1, 1);
-    int stage = 0;                       // RING3: kt % 3
     for (int kt = 0; kt < n_tiles; ++kt) {
       const int key0 = kt * KT;
       // tile kt has landed for this wave (vmcnt) and for every wave (barrier); the same barrier retires all reads
       // of the buffer the next DMA overwrites
-      const char* ks;
-      if (RING3) {
-        if (kt + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // the 4 requests of tile kt + 1 stay in flight
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const int refill = stage == 0 ? 2 : stage - 1;                              // (kt + 2) % 3 = (kt - 1) % 3
-        if (kt + 2 < n_tiles) dma_tile(kt + 2, refill);
-        ks = smem + stage * DMA_STAGE;
-        stage = stage == 2 ? 0 : stage + 1;
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < n_tiles) dma_tile(kt + 1, (kt + 1) & 1);
-        ks = smem + (kt & 1) * DMA_STAGE;
-      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt + 1 < n_tiles) dma_tile(kt + 1, (kt + 1) & 1);
+      const char* ks = smem + (kt & 1) * DMA_STAGE;
       const char* vs = ks + KD_TILE;
 
       f32x16 st[2];
@@ -552,17 +539,13 @@ extern "C" int tc_attn_d64(const TcAttnParams* pp, void* stream) {
   static const bool use_reg = [] { const char* e = getenv("TC_ATTN_STAGE"); return e && e[0] == 'r'; }();
   const bool fits = (int64_t)p.lk * p.k_ss * 2 < 0x7fffff00LL && (int64_t)p.lk * p.v_ss * 2 < 0x7fffff00LL &&
                     p.k_ss >= 64 && p.v_ss >= 64;
-  // TC_ATTN_RING = 3: three-stage K/V ring, two tiles in flight; 2 (default until measured): two stages; read per call
-  const bool ring3 = [] { const char* e = getenv("TC_ATTN_RING"); return e && e[0] == '3'; }();
   if (dual) {
     const bool fits2 = (int64_t)p.lk2 * p.k2_ss * 2 < 0x7fffff00LL && (int64_t)p.lk2 * p.v2_ss * 2 < 0x7fffff00LL &&
                        p.k2_ss >= 64 && p.v2_ss >= 64;
     if (!fits || !fits2) return TC_ESHAPE;
-    if (ring3) hipLaunchKernelGGL((attn_d64_dma_kernel<true, true>), grid, block, 0, reinterpret_cast<hipStream_t>(stream), p);
-    else hipLaunchKernelGGL((attn_d64_dma_kernel<true, false>), grid, block, 0, reinterpret_cast<hipStream_t>(stream), p);
+    hipLaunchKernelGGL(attn_d64_dma_kernel<true>, grid, block, 0, reinterpret_cast<hipStream_t>(stream), p);
   } else if (!use_reg && fits) {
-    if (ring3) hipLaunchKernelGGL((attn_d64_dma_kernel<false, true>), grid, block, 0, reinterpret_cast<hipStream_t>(stream), p);
-    else hipLaunchKernelGGL((attn_d64_dma_kernel<false, false>), grid, block, 0, reinterpret_cast<hipStream_t>(stream), p);
+    hipLaunchKernelGGL(attn_d64_dma_kernel<false>, grid, block, 0, reinterpret_cast<hipStream_t>(stream), p);
   } else {
     hipLaunchKernelGGL(attn_d64_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream), p);
   }

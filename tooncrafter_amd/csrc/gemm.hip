@@ -41,6 +41,10 @@ constexpr int BK = TC_BK;
 // re-requested as soon as every wave has consumed it) with counted s_waitcnt vmcnt + raw s_barrier -- a __syncthreads()
 // would drain the LDS-DMA queue (cdna_hip_programming.md, "Pipelining across barriers").  The plain loop has ONE K-step
 // in flight behind vmcnt(0) + barrier: with K = 320-1280 a tile's life is mostly exposed load latency.
+// (Measured on top of this loop and NOT kept, profiles/r03_*: starting the second block of each CU half a tile late
+// (0.73-1.02x: co-resident blocks are not in lock-step), and two output tiles per block back to back so that the first
+// tile's store acknowledgements arrive under the second K loop (0.90-1.09x where the grid stays >= 512 blocks, 0.57-0.85x
+// where it does not).)
 template <int N>
 __device__ __forceinline__ void gemm_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -99,11 +103,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams pin, co
     b_voff[i] = n < p.n ? (uint32_t)((int64_t)n * p.ldw * 2 + chunk * 16) : TC_OOB;
   }
   const bool k_ragged = (p.k & (BK - 1)) != 0;      // linear layers only (conv K is a multiple of 64)
+#if defined(TC_ABLATE) && (TC_ABLATE & 2)
+  const int kb_first = blockIdx.y * (((p.k + BK - 1) / BK + splits - 1) / splits);
+#endif
 
   // issue the loads of K-step kb into `stage`: scalar K offset, per-lane row offsets fixed for the whole
   // block, out-of-range rows / taps / K-tails write zeros -- no staging registers, no ds_write pass, and
   // nothing here costs VALU in the steady state
   auto load_tile = [&](int kb, int stage) {
+#if defined(TC_ABLATE) && (TC_ABLATE & 2)      // ... without the tile loads of the steady state
+    if (kb >= kb_first + 2) return;
+#endif
     const int k0 = kb * BK;
     uint32_t a_voff[RA], a_soff;
     ag.offsets(p, k0, chunk, a_voff, a_soff);
@@ -146,6 +156,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams pin, co
         b[j] = *reinterpret_cast<const bf16x8*>(sb + lds_off(wn * 32 * TN + j * 32 + frow, c));
     };
     auto mfmas = [&](bf16x8 (&a)[TM], bf16x8 (&b)[TN]) {
+#if defined(TC_ABLATE) && (TC_ABLATE & 1)      // scripts/ablate_gemm.sh: time the kernel without its MFMAs
+      asm volatile("" ::"v"(a[0]), "v"(b[0]));
+      return;
+#endif
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -224,6 +238,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams pin, co
 
   // ---- epilogue: accumulators -> LDS fp32 [BM][BN] -> row vectors
   float* cs = reinterpret_cast<float*>(smem);
+#if defined(TC_ABLATE) && (TC_ABLATE & 4)      // ... without the epilogue (one guarded store keeps the accumulators live)
+  {
+    float t = 0.f;
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+    if (t == 1.2345e30f) reinterpret_cast<float*>(p.c)[tid] = t;
+    return;
+  }
+#endif
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll

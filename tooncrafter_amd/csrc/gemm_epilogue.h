@@ -124,7 +124,11 @@ __device__ __forceinline__ void epilogue_fast(const TcGemmParams& p, const float
       for (int e = 0; e < 4; ++e) { gt[e] = lo[e]; gt[4 + e] = hi[e]; }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
+#if defined(TC_ABLATE) && (TC_ABLATE & 8)      // scripts/ablate_gemm.sh: the GEGLU epilogue without its erf
+        if (PLAIN) x[e] = (x[e] + bv[e]) * (gt[e] + bg[e]);
+#else
         if (PLAIN) x[e] = (x[e] + bv[e]) * gelu_erf_f(gt[e] + bg[e]);
+#endif
         else x[e] = (x[e] * p.alpha + bv[e]) * gelu_erf_f(gt[e] * p.alpha + bg[e]) * p.out_scale;
       }
     } else {
@@ -144,7 +148,11 @@ __device__ __forceinline__ void epilogue_fast(const TcGemmParams& p, const float
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] += rf[e];
     }
+#if defined(TC_ABLATE) && (TC_ABLATE & 16)     // ... without its global stores
+    if (x[0] == 1.2345e30f) {
+#else
     if (m < p.m) {
+#endif
       if (p.out_f32) {
         float* op = reinterpret_cast<float*>(c_base) + (int64_t)m * p.ldc + n0;
         *reinterpret_cast<f32x4*>(op) = f32x4{x[0], x[1], x[2], x[3]};

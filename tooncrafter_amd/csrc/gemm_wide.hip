@@ -303,13 +303,9 @@ void launch_wide(const TcGemmParams& p, dim3 grid, hipStream_t s) {
 #undef TC_LAUNCH_WIDE
 }
 
-int wide_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("TC_GEMM_WIDE");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v;
+int wide_enabled() {        // TC_GEMM_WIDE=0: never (read per call: A/B runs flip it inside one process)
+  const char* e = getenv("TC_GEMM_WIDE");
+  return (e && e[0] == '0') ? 0 : 1;
 }
 
 }  // namespace
