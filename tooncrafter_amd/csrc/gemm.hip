@@ -41,6 +41,10 @@ constexpr int BK = TC_BK;
 // re-requested as soon as every wave has consumed it) with counted s_waitcnt vmcnt + raw s_barrier -- a __syncthreads()
 // would drain the LDS-DMA queue (cdna_hip_programming.md, "Pipelining across barriers").  The plain loop has ONE K-step
 // in flight behind vmcnt(0) + barrier: with K = 320-1280 a tile's life is mostly exposed load latency.
+// (A per-wave epilogue -- private swizzled slabs, no block barrier, GEGLU evaluated in the accumulator layout after
+// v_permlane16_swap so that only the product crosses LDS -- was built, bit-identical in 12 epilogue cases, and measured
+// 1.01-1.02x on the GEGLU layers and 0.84-0.99x on the plain ones (128-byte instead of 256-byte row segments per store
+// instruction), profiles/r03_wave_epilogue_ab.txt: the LDS transpose is not what the epilogue waits for.  Removed.)
 // (Measured on top of this loop and NOT kept, profiles/r03_*: starting the second block of each CU half a tile late
 // (0.73-1.02x: co-resident blocks are not in lock-step), and two output tiles per block back to back so that the first
 // tile's store acknowledgements arrive under the second K loop (0.90-1.09x where the grid stays >= 512 blocks, 0.57-0.85x
