@@ -85,6 +85,9 @@ def test_gemm_ws_vs_spec(hip, emu, m, n, geglu, res, ln):
     with ws_mode(3):                                           # vmcnt(0) waits: same arithmetic, same bits
         safe = hip.gemm(a, w, bias, **kw)
     assert torch.equal(out, safe), "counted-vmcnt and vmcnt(0) runs differ: a tile was read before it landed"
+    with ws_mode(4):                                           # deeper store window (the default count of the heuristic)
+        deep = hip.gemm(a, w, bias, **kw)
+    assert torch.equal(out, deep), "the deeper store window changed the result: a tile was read before it landed"
 
 
 def test_gemm_ws_strided_views_and_bounds(hip, emu):

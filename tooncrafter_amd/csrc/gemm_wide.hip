@@ -333,7 +333,9 @@ int tc_gemm_wide_try(const TcGemmParams& p, int batch, hipStream_t s, bool force
   if (!force) {
     const bool fits = blocks >= 192 && blocks <= 256;
     const bool conv_like = p.n >= 256 && p.k >= 2048 && (blocks >= 1024 || fits);
-    const bool wide_geglu = geglu && p.n >= 5120 && p.k >= 1280;
+    // (r02: wide GEGLU layers -- N = 10240, K = 1280 -- took the 256x320 tile; with two K-steps in flight the 128x128 kernel
+    // is ahead there too: 157-160 us vs 163-171 us, profiles/r03_pipe_bench.txt / r03_two_tiles_per_block_ab.txt)
+    const bool wide_geglu = false;
     if (!conv_like && !wide_geglu) return 0;
   }
   const int64_t nblk = (int64_t)tiles_n * 8 * ((tiles_m + 7) / 8);

@@ -316,7 +316,9 @@ int tc_gemm_ws_try(const TcGemmParams& p, int batch, hipStream_t s) {
   if (nchunks < 1) nchunks = 1;
   if (nchunks > ntiles) nchunks = ntiles;
   const int grid = slabs * 8 * ((nchunks + 7) / 8);
-  const int safe = mode == 3 ? 1 : (mode >= 4 ? 2 : 0);
+  // wait mode: the heuristic (1) runs with the deeper store window (+1-6 %, profiles/r03_ws_bench_hipblaslt_yardstick.txt);
+  // 2 = counted waits that also retire the stores of two tiles ago, 3 = vmcnt(0) everywhere (parity tests)
+  const int safe = mode == 3 ? 1 : (mode == 2 ? 0 : 2);
   const bool res = p.residual != nullptr, ln = p.a_norm != 0;
   dim3 g((unsigned)grid), b(256);
 #define TC_WS_LAUNCH(NT, G, R, L) hipLaunchKernelGGL((gemm_ws_kernel<NT, G, R, L>), g, b, 0, s, p, nchunks, safe)
