@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const TcGemmParams p
 // their 64x64-tile launch, while K <= 5120 (linear, temporal conv) loses -- those keep the 64x64 tiles.
 // TC_GEMM_SPLITK=n forces n (tuning), 0 disables.
 static int tc_gemm_splits(const TcGemmParams& p) {
-  static const int force = [] { const char* e = getenv("TC_GEMM_SPLITK"); return e ? atoi(e) : -1; }();
+  const int force = [] { const char* e = getenv("TC_GEMM_SPLITK"); return e ? atoi(e) : -1; }();     // per call (sweeps)
   const int batch = p.batch > 0 ? p.batch : 1;
   if (force == 0 || batch != 1 || p.act == TC_ACT_GEGLU || (p.n & 7) != 0) return 1;
   const int nk = (p.k + BK - 1) / BK;
@@ -331,6 +331,9 @@ static int tc_gemm_splits(const TcGemmParams& p) {
   int s = force > 0 ? force : (int)(512 / tiles);
   if (s > 8) s = 8;
   if (s > nk / 8) s = nk / 8;
+  // a power of two: at 100 tiles (the level-3 convolutions) 4 slices measured 1.33-1.41x faster than 5
+  // (profiles/r03_gemm_autotune_unet.txt: 61.5 vs 82.3 us at K = 11520, 101.9 vs 143.9 us at K = 23040)
+  if (force <= 0) while (s & (s - 1)) s &= s - 1;
   return s < 2 ? 1 : s;
 }
 
@@ -349,6 +352,12 @@ static void tc_gemm_pick_tile(int m, int n, int batch, bool geglu, int* tm, int*
   const bool small = !geglu && big_tiles < 384;
   *tm = small ? 1 : 2;
   *tn = small ? 1 : 2;
+  // the 3- / 4-channel output convolutions: a 64-column tile wastes half as many MFMAs on padding (measured,
+  // profiles/r03_gemm_autotune_*.txt: decoder conv_out 1362 -> 701 us with 128x64, UNet out 106 -> 67 us with 64x64)
+  if (!geglu && n <= 64) {
+    *tn = 1;
+    *tm = m >= 262144 ? 2 : 1;
+  }
 }
 
 extern "C" int tc_gemm_bf16(const TcGemmParams* pp, void* stream) {
@@ -396,7 +405,7 @@ extern "C" int tc_gemm_bf16(const TcGemmParams* pp, void* stream) {
   if (!tc_gemm_offsets_fit(p)) return TC_ESHAPE;          // buffer-load offsets are 31-bit
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // TC_GEMM_TILE = wide | 22 | 21 | 12 | 11 forces one tile family (tuning / A-B runs); default: heuristic
-  static const int force = [] {
+  const int force = [] {                                   // per call (scripts/gemm_autotune.py sweeps it in one process)
     const char* e = getenv("TC_GEMM_TILE");
     if (!e) return 0;
     if (e[0] == 'w') return 1;
