@@ -209,20 +209,29 @@ class NormProbe:
 PEAK_HBM_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def measure_roofline_hbm(model, inp):
+def guided_forward(model, inp):
+    """The B = 2 (cond + uncond) UNet call of one DDIM step exactly as `apply_model_multi` issues it: with the shared
+    prefix (lvdm/common.py: CfgShare) the latent-side inputs are handed over ONCE and `replicas=2`."""
     un = model.model.diffusion_model
-    x2, cc2 = torch.cat([inp["x_T"]] * 2), torch.cat([inp["c_concat"]] * 2)
+    n = 1 if getattr(model, "cfg_share", False) else 2
+    x, cc = torch.cat([inp["x_T"]] * n), torch.cat([inp["c_concat"]] * n)
     ctx2 = torch.cat([inp["cond"], inp["uncond"]])
-    ts = torch.full((2,), 499, device=x2.device, dtype=torch.long)
-    fs2 = torch.cat([inp["fs"]] * 2)
+    ts = torch.full((n,), 499, device=x.device, dtype=torch.long)
+    fs = torch.cat([inp["fs"]] * n)
+    return lambda: un(None, ts, context=ctx2, fs=fs, x_parts=[x, cc], replicas=2 if n == 1 else 1)
+
+
+def measure_roofline_hbm(model, inp):
+    fwd = guided_forward(model, inp)
+    x2 = inp["x_T"]
     with torch.no_grad():
-        un(None, ts, context=ctx2, fs=fs2, x_parts=[x2, cc2])
+        fwd()
         torch.cuda.synchronize()
         big = torch.empty((8192, 8192), device=x2.device, dtype=torch.bfloat16).normal_()
         for _ in range(6):
             big @ big
         with NormProbe(ops.backend()) as probe:
-            un(None, ts, context=ctx2, fs=fs2, x_parts=[x2, cc2])
+            fwd()
         n, ms, by = probe.summary()
     gbs = by / (ms * 1e-3) / 1e9
     name, tj = _pmc_file("r03_pmc_gn_traffic.json")
@@ -278,7 +287,7 @@ def measure_roofline(model, inp):
     dec.use_hipgraph = False
     try:
         with torch.no_grad():
-            n_f, ms_f, fl_f = probe(lambda: un(None, ts, context=ctx2, fs=fs2, x_parts=[x2, cc2]))
+            n_f, ms_f, fl_f = probe(guided_forward(model, inp))
             n_16, ms_16, fl_16 = probe(lambda: dec.decode_clip(z16, inp["refs"], scale=1.0 / 0.18215))
             n_14, ms_14, fl_14 = probe(lambda: dec.decode_clip(z14, inp["refs"], scale=1.0 / 0.18215))
     finally:
@@ -334,7 +343,7 @@ def measure_boundary(model, inp):
         return (time.perf_counter() - t0) / reps * 1e3
     out = {}
     with torch.no_grad():
-        un_fwd = lambda: un(None, ts, context=ctx2, fs=fs2, x_parts=[x2, cc2])
+        un_fwd = guided_forward(model, inp)
         out["unet_fwd_b2_eager_ms"] = round(wall(un_fwd), 2)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):

@@ -66,11 +66,7 @@ def main():
             model.first_stage_model.decoder.use_hipgraph = False
             model.decode_first_stage(z, ref_context=inp["refs"])
         else:
-            un = model.model.diffusion_model
-            x2, cc2 = torch.cat([inp["x_T"]] * 2), torch.cat([inp["c_concat"]] * 2)
-            ctx2 = torch.cat([inp["cond"], inp["uncond"]])
-            ts = torch.full((2,), 499, device=dev, dtype=torch.long)
-            un(None, ts, context=ctx2, fs=torch.cat([inp["fs"]] * 2), x_parts=[x2, cc2])
+            bench.guided_forward(model, inp)()
     hip.gemm = real
     torch.cuda.synchronize()
     print(hip.lib.tc_build_info().decode(), torch.cuda.get_device_name(0))

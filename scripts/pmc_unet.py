@@ -15,7 +15,8 @@ ctx2 = torch.cat([inp["cond"], inp["uncond"]])
 ts = torch.full((2,), 499, device=dev, dtype=torch.long)
 fs2 = torch.cat([inp["fs"]] * 2)
 with torch.no_grad():
+    fwd = bench.guided_forward(model, inp)        # as apply_model_multi issues it (shared CFG prefix)
     for _ in range(n):
-        un(None, ts, context=ctx2, fs=fs2, x_parts=[x2, cc2])
+        fwd()
 torch.cuda.synchronize()
 print("forwards", n)

@@ -1,0 +1,78 @@
+"""Batched classifier-free guidance with the shared prefix (lvdm/common.py: CfgShare): the n guided passes of a sampler
+step have the same latent, concat conditioning, timestep and fps, so the UNet runs what precedes its first cross-attention
+once and repeats the rows there.  `replicas=n` on single-copy inputs must equal the plain batch-(n b) call on repeated
+inputs -- the reference's n separate `apply_model` calls (ddim.py:226-233) -- and the sampler must only take the short cut
+when the passes really share their concat conditioning."""
+import pytest
+import torch
+
+from conftest import TINY_UNET_CFG, sub_state_dict
+from emu_ops import EmuOps
+from tooncrafter_amd import ops, synth
+from tooncrafter_amd.lvdm.openaimodel3d import UNetModel
+
+
+@pytest.fixture()
+def emu_backend():
+    # fp32 emulation WITHOUT the bf16 rounding of every operator result: the statement is about the arithmetic being the
+    # same, and on the tiny net a rounding flipped by torch's batch-dependent summation order shows up at the 1e-2 level
+    old = ops.set_backend(EmuOps(round_bf16=False))
+    yield
+    ops.set_backend(old)
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_unet_replicas_equals_repeated_batch(tiny_sd, emu_backend, n):
+    un = UNetModel(**TINY_UNET_CFG).eval()
+    un.load_state_dict(sub_state_dict(tiny_sd, "model.diffusion_model."), strict=True)
+    b, t, h, w = 2, 4, 8, 8
+    inp = synth.synth_inputs(b, t, h, w, context_dim=TINY_UNET_CFG["context_dim"], seed=3)
+    ctx = torch.cat([inp["cond"]] + [inp["uncond"] * (1.0 + 0.1 * k) for k in range(n - 1)], 0)
+    ts = torch.tensor([601, 33])
+    with torch.no_grad():
+        full = un(None, ts.repeat(n), context=ctx, fs=inp["fs"].repeat(n),
+                  x_parts=[inp["x_T"].repeat(n, 1, 1, 1, 1), inp["c_concat"].repeat(n, 1, 1, 1, 1)])
+        un.reset_conditioning()
+        shared = un(None, ts, context=ctx, fs=inp["fs"], x_parts=[inp["x_T"], inp["c_concat"]], replicas=n)
+    assert shared.shape == full.shape == (n * b, 4, t, h, w)
+    assert not torch.equal(full[:b], full[b:2 * b])                      # the passes do differ (through the context)
+    assert torch.allclose(shared, full, rtol=0, atol=2e-5 * float(full.abs().max()))
+
+
+def test_replicas_needs_matching_context(tiny_sd, emu_backend):
+    un = UNetModel(**TINY_UNET_CFG).eval()
+    un.load_state_dict(sub_state_dict(tiny_sd, "model.diffusion_model."), strict=True)
+    inp = synth.synth_inputs(1, 4, 8, 8, context_dim=TINY_UNET_CFG["context_dim"], seed=4)
+    with pytest.raises(ValueError):
+        un(None, torch.tensor([5]), context=inp["cond"], fs=inp["fs"], x_parts=[inp["x_T"], inp["c_concat"]], replicas=2)
+
+
+def test_apply_model_multi_shares_only_identical_concat(tiny_sd, emu_backend):
+    """`uc` built from the SAME c_concat tensor (inference.py:213-214) takes the shared prefix; a different tensor with
+    different values must not -- and both must equal the per-pass calls."""
+    from test_two_clips import _pipeline
+    model = _pipeline(tiny_sd, "cpu")
+    model.use_hipgraph = False
+    inp = synth.synth_inputs(1, 4, 8, 8, context_dim=96, seed=5)
+    t = torch.tensor([401])
+    seen = []
+    real = model.model.diffusion_model.forward
+
+    def spy(*a, **kw):
+        seen.append(kw.get("replicas", 1))
+        return real(*a, **kw)
+    model.model.diffusion_model.forward = spy
+    cond = {"c_crossattn": [inp["cond"]], "c_concat": [inp["c_concat"]]}
+    with torch.no_grad():
+        for other_concat, want in ((inp["c_concat"], 2), (inp["c_concat"] * 0.5, 1)):
+            uc = {"c_crossattn": [inp["uncond"]], "c_concat": [other_concat]}
+            model.reset_conditioning()
+            seen.clear()
+            e_c, e_u = model.apply_model_multi(inp["x_T"], t, [cond, uc], fs=inp["fs"])
+            assert seen == [want]
+            model.reset_conditioning()
+            model.cfg_share = False
+            r_c, r_u = model.apply_model_multi(inp["x_T"], t, [cond, uc], fs=inp["fs"])
+            model.cfg_share = True
+            scale = float(r_c.abs().max())
+            assert torch.allclose(e_c, r_c, rtol=0, atol=2e-5 * scale) and torch.allclose(e_u, r_u, rtol=0, atol=2e-5 * scale)

@@ -23,7 +23,7 @@ import torch.nn as nn
 
 from .. import ops
 from .._lib import ACT_GEGLU
-from .common import Act, PackedModule, SourceKey, f32, fold_layernorm, pack_geglu, pack_linear
+from .common import Act, CfgShare, PackedModule, SourceKey, f32, fold_layernorm, pack_geglu, pack_linear
 
 
 class ContextCache:
@@ -265,13 +265,20 @@ class BasicTransformerBlock(PackedModule):
             return x, self._folded(i, kind)
         return self._ln(x, i, consumer if kind != "q" else None, gated), None
 
-    def forward_spatial(self, x, act: Act, ctx: ContextCache):
+    def forward_spatial(self, x, act: Act, ctx: ContextCache, share: CfgShare = None):
+        """`share` (first block of the UNet's first spatial transformer under batched guidance): x / act arrive at the
+        single-copy batch; the guided passes part ways at the cross-attention, so the rows are repeated in front of it
+        and (x, expanded act) is returned."""
         h, ln = self._pre(x, 1, self.attn1.pk["wqkv"], "qkv")
         x = self.attn1.forward_spatial_self(h, x, act, ln=ln)
+        if share is not None:
+            x, act = x.repeat(share.n, 1), share.expand(act)
+            share.done = True
         h, ln = self._pre(x, 2, self.attn2.pk["wq"], "q")
         x = self.attn2.forward_cross(h, x, act, ctx, ln=ln)
         h, ln = self._pre(x, 3, self.ff.pk["w1"], "ff")
-        return self.ff(h, x, ln=ln)
+        out = self.ff(h, x, ln=ln)
+        return out if share is None else (out, act)
 
     def forward_temporal(self, x, act: Act):
         h, ln = self._pre(x, 1, self.attn1.pk["wqkv"], "qkv")
@@ -305,12 +312,15 @@ class SpatialTransformer(PackedModule):
                 "wi": pack_linear(self.proj_in.weight), "bi": f32(self.proj_in.bias),
                 "wo": pack_linear(self.proj_out.weight), "bo": f32(self.proj_out.bias)}
 
-    def forward(self, act: Act, ctx: ContextCache) -> Act:
+    def forward(self, act: Act, ctx: ContextCache, share: CfgShare = None) -> Act:
         pk = self.pk
         h = ops.groupnorm(act.rows, pk["gn_g"], pk["gn_b"], samples=act.frames, rows=act.hw, eps=1e-6)
         h = ops.gemm(h, pk["wi"], pk["bi"])
         for blk in self.transformer_blocks:
-            h = blk.forward_spatial(h, act, ctx)
+            if share is not None and not share.done:
+                h, act = blk.forward_spatial(h, act, ctx, share)        # act: now the n-fold batch (proj_out's residual)
+            else:
+                h = blk.forward_spatial(h, act, ctx)
         return act.like(ops.gemm(h, pk["wo"], pk["bo"], residual=act.rows))
 
 

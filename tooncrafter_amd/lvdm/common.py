@@ -40,6 +40,24 @@ class Act:
         return Act(rows, self.b, self.t, self.h if h is None else h, self.w if w is None else w)
 
 
+class CfgShare:
+    """Batched classifier-free guidance: the n passes of one sampler step (cond, uncond[, image-only]; reference
+    ddim.py:226-233, ddim_multiplecond.py:226-236 run them as n UNet calls) get the SAME latent, concat conditioning,
+    timestep and fps -- they differ only through the cross-attention context.  Everything in front of the first
+    cross-attention (input conv, the initial temporal transformer, the first ResBlock + temporal convolutions, the first
+    spatial self-attention) therefore computes n identical copies: it runs ONCE at batch b and is repeated where the
+    paths part.  Exact (the identical copies were bit-identical to begin with: no cross-sample term anywhere)."""
+
+    def __init__(self, n: int, emb1: torch.Tensor):
+        self.n, self.emb1, self.embn, self.done = n, emb1, emb1.repeat(n, 1), False
+
+    def emb(self) -> torch.Tensor:
+        return self.embn if self.done else self.emb1
+
+    def expand(self, act: "Act") -> "Act":
+        return Act(act.rows.repeat(self.n, 1), act.b * self.n, act.t, act.h, act.w)
+
+
 class SourceKey:
     """Identity of the tensors a cache was filled from.  Holds STRONG references, so the caching
     allocator cannot recycle their storage under a new tensor while the cache lives, and compares by

@@ -170,6 +170,7 @@ class LatentDiffusion(DDPM):
         # batched-CFG state: static 2B inputs (+ the captured hipGraph of the UNet forward)
         self._cfg_state = None
         self.use_hipgraph = os.environ.get("TC_HIPGRAPH", "1") != "0"
+        self.cfg_share = os.environ.get("TC_CFG_SHARE", "1") != "0"
 
     def _instantiate_cond_stage(self, config):
         model = instantiate_from_config(config)
@@ -224,17 +225,24 @@ class LatentDiffusion(DDPM):
         # identity of the conditioning: the tensor OBJECTS (strong references held by SourceKey) and their
         # versions -- never data_ptr(), which the next clip's freshly allocated tensors can share
         cond_t = [tns for c in conds for tns in (*c["c_crossattn"], *c["c_concat"])] + [fs]
-        shape_sig = (n, tuple(x_noisy.shape), x_noisy.device)
+        # every pass has the same latent, timestep and fps; when they also share the concat conditioning (the SAME tensor
+        # objects: inference.py:213-214 builds `uc` from the very `img_cat_cond` of `cond`) they differ only through the
+        # cross-attention context and the UNet computes what precedes it once (common.CfgShare; TC_CFG_SHARE=0: off)
+        share = n > 1 and self.cfg_share and all(
+            len(c["c_concat"]) == len(conds[0]["c_concat"]) and all(a is b0 for a, b0 in zip(c["c_concat"], conds[0]["c_concat"]))
+            for c in conds[1:])
+        shape_sig = (n, tuple(x_noisy.shape), x_noisy.device, share)
         st = self._cfg_state
         unet = self.model.diffusion_model
         if st is None or st["key"] is None or st["shape_sig"] != shape_sig or not st["key"].same(cond_t):
             # conditioning changed (new clip): (re)fill the static batch-nB inputs; same-shape buffers are
             # reused so that a captured graph stays valid
-            cat = lambda key: torch.cat([torch.cat(c[key], 1) for c in conds], dim=0)
-            ctx2, cc2 = cat("c_crossattn"), cat("c_concat").to(torch.float32)
-            fs2 = None if fs is None else torch.cat([fs] * n, dim=0)
+            cat = lambda key, cs: torch.cat([torch.cat(c[key], 1) for c in cs], dim=0)
+            nx = 1 if share else n                     # copies of the latent-side inputs the UNet is handed
+            ctx2, cc2 = cat("c_crossattn", conds), cat("c_concat", conds[:nx]).to(torch.float32)
+            fs2 = None if fs is None else torch.cat([fs] * nx, dim=0)
             if st is not None and st["ctx2"].shape == ctx2.shape and st["x2"].shape[1:] == x_noisy.shape[1:] \
-                    and st["x2"].shape[0] == n * b and st["x2"].device == x_noisy.device \
+                    and st["x2"].shape[0] == nx * b and st["x2"].device == x_noisy.device \
                     and (st["fs2"] is None) == (fs2 is None):
                 st["ctx2"].copy_(ctx2)
                 st["cc2"].copy_(cc2)
@@ -243,16 +251,17 @@ class LatentDiffusion(DDPM):
             else:
                 st = self._cfg_state = dict(
                     ctx2=ctx2.contiguous(), cc2=cc2.contiguous(), fs2=fs2,
-                    x2=torch.empty((n * b, *x_noisy.shape[1:]), dtype=torch.float32, device=x_noisy.device),
-                    ts2=torch.empty((n * b,), dtype=torch.long, device=x_noisy.device), graph=None, calls=0)
+                    x2=torch.empty((nx * b, *x_noisy.shape[1:]), dtype=torch.float32, device=x_noisy.device),
+                    ts2=torch.empty((nx * b,), dtype=torch.long, device=x_noisy.device), graph=None, calls=0)
             st["key"], st["shape_sig"] = SourceKey(cond_t), shape_sig
             unet.context_cache(st["ctx2"], x_noisy.shape[2])          # project K/V now (in place if cached)
-        for k in range(n):
+        for k in range(1 if share else n):
             st["x2"][k * b:(k + 1) * b].copy_(x_noisy)
             st["ts2"][k * b:(k + 1) * b].copy_(t)
 
         def fwd():
-            return unet(None, st["ts2"], context=st["ctx2"], fs=st["fs2"], x_parts=[st["x2"], st["cc2"]])
+            return unet(None, st["ts2"], context=st["ctx2"], fs=st["fs2"], x_parts=[st["x2"], st["cc2"]],
+                        replicas=n if share else 1)
 
         if self.use_hipgraph and x_noisy.is_cuda:
             # a captured graph replays the kernels and the packed-weight pointers it recorded: new weights

@@ -21,7 +21,7 @@ import torch.nn as nn
 from .. import ops
 from .._lib import ACT_SILU
 from .attention import ContextCache, SpatialTransformer, TemporalTransformer
-from .common import Act, PackedModule, ceil_to, f32, pack_conv3x3, pack_convt3, pack_linear
+from .common import Act, CfgShare, PackedModule, ceil_to, f32, pack_conv3x3, pack_convt3, pack_linear
 
 
 def conv_nd(dims, *args, **kwargs):
@@ -160,12 +160,14 @@ class ResBlock(TimestepBlock, PackedModule):
 
 
 class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
-    def forward(self, act: Act, emb_all, ctx: Optional[ContextCache] = None) -> Act:
+    def forward(self, act: Act, emb_all, ctx: Optional[ContextCache] = None, share=None) -> Act:
+        """`share` (common.CfgShare): under batched guidance the layers in front of the first cross-attention see the
+        single-copy batch; `emb_all` is then taken from it (single-copy rows before the split, n-fold after)."""
         for layer in self:
             if isinstance(layer, ResBlock):
-                act = layer(act, emb_all)
+                act = layer(act, emb_all if share is None else share.emb())
             elif isinstance(layer, SpatialTransformer):
-                act = layer(act, ctx)
+                act = layer(act, ctx, share if share is not None and not share.done else None)
             elif isinstance(layer, TemporalTransformer):
                 act = layer(act)
             elif isinstance(layer, InputConv):
@@ -343,33 +345,46 @@ class UNetModel(PackedModule):
         return ops.gemm(semb, pk["emb_w"], pk["emb_b"], out_f32=True)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, timesteps, context=None, features_adapter=None, fs=None, x_parts=None, **kwargs):
+    def forward(self, x, timesteps, context=None, features_adapter=None, fs=None, x_parts=None, replicas=1, **kwargs):
         """x: (B, in_channels, T, H, W) fp32 (or `x_parts` = [x, c_concat] to skip the torch.cat of
         the hybrid conditioning); timesteps: [B] long; context: (B, 77+16T, Cc); fs: [B] long.
-        Extra kwargs are swallowed like the reference does (openaimodel3d.py:548)."""
+        Extra kwargs are swallowed like the reference does (openaimodel3d.py:548).
+
+        `replicas` = n > 1 (batched classifier-free guidance, ddpm3d.apply_model_multi): x / timesteps / fs describe ONE
+        copy of batch b, `context` all n * b; the result has batch n * b as if the copy had been repeated n times, but the
+        layers in front of the first cross-attention run once (common.CfgShare)."""
         if features_adapter is not None:
             raise NotImplementedError("features_adapter is unused by the inference path")
         parts = x_parts if x_parts is not None else [x]
         b, _, t, hh, ww = parts[0].shape
+        if replicas > 1 and (context is None or context.shape[0] != replicas * b):
+            raise ValueError(f"replicas={replicas}: context must carry {replicas * b} samples")
         cin_pad = ceil_to(self.in_channels, 64)
         rows = ops.nchw_to_rows(parts[0], parts[1] if len(parts) > 1 else None, c_pad=cin_pad)
         act = Act(rows, b, t, hh, ww)
         ctx = self.context_cache(context, t)
         emb_all = self._embedding(timesteps, fs, b)
+        share = CfgShare(replicas, emb_all) if replicas > 1 else None
 
         hs = []
         for i, module in enumerate(self.input_blocks):
-            act = module(act, emb_all, ctx)
+            act = module(act, emb_all, ctx, share)
             if i == 0 and self.addition_attention:
-                act = self.init_attn(act, emb_all, ctx)
+                act = self.init_attn(act, emb_all, ctx)            # a TemporalTransformer: no context, no embedding
             hs.append(act)
+        if share is not None:
+            if not share.done:
+                raise NotImplementedError("replicas > 1 needs a cross-attention in the input blocks to part the passes at")
+            emb_all = share.embn
         act = self.middle_block(act, emb_all, ctx)
         for module in self.output_blocks:
             skip = hs.pop()
+            if skip.b != act.b:                                    # the skip taken in front of the split: repeat it now
+                skip = share.expand(skip)
             act = act.like(ops.concat_rows(act.rows, skip.rows))
             act = module(act, emb_all, ctx)
         pk = self.pk
         h = ops.groupnorm(act.rows, pk["og"], pk["ob"], samples=act.frames, rows=act.hw, eps=1e-5, silu=True)
         geom, _, _ = _conv_geom(act, act.c)
         y = ops.gemm(h, pk["ow"], pk["ocb"], conv=geom, out_f32=True)
-        return ops.rows_to_nchw(y, c=self.out_channels, b=b, t=t, h=act.h, w=act.w)
+        return ops.rows_to_nchw(y, c=self.out_channels, b=act.b, t=t, h=act.h, w=act.w)
