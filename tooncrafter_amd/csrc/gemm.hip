@@ -45,6 +45,10 @@ constexpr int BK = TC_BK;
 // v_permlane16_swap so that only the product crosses LDS -- was built, bit-identical in 12 epilogue cases, and measured
 // 1.01-1.02x on the GEGLU layers and 0.84-0.99x on the plain ones (128-byte instead of 256-byte row segments per store
 // instruction), profiles/r03_wave_epilogue_ab.txt: the LDS transpose is not what the epilogue waits for.  Removed.)
+// (A persistent form -- a block walks a strided sequence of tiles and requests the next tile's first K-step under the
+// current tile's epilogue: two-pass transpose through one stage, static buffer-store count, counted vmcnt across the
+// tile boundary -- was built, bit-identical in 13 cases, and measured 0.90-1.04x on every short-K shape,
+// profiles/r03_persistent_gemm_ab.txt: the exposed first-load latency is not what the tile waits for either.  Removed.)
 // (Measured on top of this loop and NOT kept, profiles/r03_*: starting the second block of each CU half a tile late
 // (0.73-1.02x: co-resident blocks are not in lock-step), and two output tiles per block back to back so that the first
 // tile's store acknowledgements arrive under the second K loop (0.90-1.09x where the grid stays >= 512 blocks, 0.57-0.85x
