@@ -110,8 +110,8 @@ def _install_shims() -> None:
 def _install_torchvision_shim() -> None:
     """The slice of torchvision the reference's inference script touches (inference.py:9-10,65-69,126-133,
     154-155): PIL-based Resize / CenterCrop / ToTensor / Normalize / Compose, utils.make_grid and io.write_video.
-    No video encoder exists on such an image, so write_video stores the uint8 frames as `.npy` next to the
-    path the `.mp4` would have had (the same fallback as tooncrafter_amd.output.default_writer)."""
+    No encoder library exists on such an image, so write_video goes through tooncrafter_amd.mp4 -- a real H.264 `.mp4`
+    under the name the script asked for, every macroblock I_PCM (the same fallback as output.default_writer)."""
     import os
 
     import numpy as np
@@ -189,10 +189,14 @@ def _install_torchvision_shim() -> None:
     io = types.ModuleType("torchvision.io")
 
     def write_video(filename, video_array, fps, video_codec="h264", options=None, **kw):
-        alt = os.path.splitext(filename)[0] + ".npy"
-        os.makedirs(os.path.dirname(alt) or ".", exist_ok=True)
-        np.save(alt, torch.as_tensor(video_array).cpu().numpy())
-        return alt
+        from .mp4 import write_mp4
+        frames = torch.as_tensor(video_array).cpu()
+        os.makedirs(os.path.dirname(filename) or ".", exist_ok=True)
+        if frames.shape[1] % 2 or frames.shape[2] % 2:           # yuv420p needs even sizes: keep the raw frames instead
+            alt = os.path.splitext(filename)[0] + ".npy"
+            np.save(alt, frames.numpy())
+            return alt
+        return write_mp4(filename, frames, int(fps))
 
     io.write_video = write_video
     tv.transforms, tv.utils, tv.io = tr, ut, io

@@ -7,8 +7,9 @@ and the multi-GPU gather move one byte per sample instead of four.
 
 h264 encoding is not part of the accelerated path: the frames go to `torchvision.io.write_video`
 when torchvision is installed (as in the reference), to a caller-supplied `writer`, or -- on images
-without a video encoder, like the build container -- to an uncompressed `.npy` next to where the
-`.mp4` would have been.
+without a video encoder, like the build container -- through the self-contained writer of `mp4.py`:
+the same container and codec (one avc1 track, H.264), every macroblock coded as I_PCM, i.e. lossless
+after the yuv420p conversion where libx264 at crf 10 is not.
 """
 from __future__ import annotations
 
@@ -37,9 +38,13 @@ def default_writer(path: str, frames: torch.Tensor, fps: int) -> str:
         if getattr(torchvision, "__tooncrafter_shim__", False):
             raise ImportError("dropin's torchvision shim has no video encoder")
     except Exception:
-        alt = os.path.splitext(path)[0] + ".npy"
-        np.save(alt, frames.numpy())
-        return alt
+        from .mp4 import write_mp4
+        t, h, w, _ = frames.shape
+        if h % 2 or w % 2:                                    # yuv420p needs even sizes: keep the raw frames instead
+            alt = os.path.splitext(path)[0] + ".npy"
+            np.save(alt, frames.numpy())
+            return alt
+        return write_mp4(path, frames, fps)
     torchvision.io.write_video(path, frames, fps=fps, video_codec='h264', options={'crf': '10'})
     return path
 
