@@ -4,13 +4,15 @@ Mirror of reference lvdm/modules/encoders/condition.py: `FrozenOpenCLIPEmbedder`
 `FrozenOpenCLIPImageEmbedderV2` (295-372) with the same constructor kwargs and call signatures, on the HIP
 kernels (lvdm/openclip.py).  The reference builds the networks with the third-party `open_clip` package, which
 this image lacks, so they are rebuilt here from the published ViT-H/14 hyper-parameters with open_clip's
-parameter names; two host-side pieces of the reference cannot be reproduced exactly without their packages and
-say so loudly instead of guessing:
-  * tokenisation (`open_clip.tokenize`, BPE vocabulary file): `forward(text)` accepts already-tokenised
-    int64 (B, 77) tensors and the empty prompt "" (the scripts' default); other strings need `open_clip`;
-  * image resize (`kornia.geometry.resize(..., 'bicubic', align_corners=True, antialias=True)`): replaced by
-    `torch.nn.functional.interpolate(bicubic, align_corners=True, antialias=True)` -- a different antialias
-    filter, i.e. a documented deviation of the preprocessing, not of the towers.
+parameter names.  Two host-side pieces of the reference live in third-party packages that are absent too; both are
+restated from their published algorithms, parity unpinned (no golden can be made here):
+  * tokenisation (`open_clip.tokenize`, open_clip_torch 2.22.0): `lvdm/clip_tokenizer.py`; the BPE merge table is DATA
+    (open_clip's `bpe_simple_vocab_16e6.txt.gz`): with its path in `TC_CLIP_BPE_VOCAB` (or the package installed) any
+    prompt is tokenised; without it, already-tokenised int64 (B, 77) tensors and the empty prompt "" (the scripts'
+    default, whose tokens do not depend on the table) are accepted and other strings raise;
+  * image resize (`kornia.geometry.resize(x, (224, 224), 'bicubic', align_corners=True, antialias=True)`, kornia
+    unpinned in requirements.txt): `kornia_resize` below -- kornia's antialias is a Gaussian blur sized from the
+    scale factor in front of a plain bicubic interpolation (NOT torch's antialias=True filter).
 """
 from __future__ import annotations
 
@@ -19,6 +21,35 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .openclip import _VisualHolder, build_text
+
+
+def _gaussian_kernel1d(ks: int, sigma: float, device, dtype) -> torch.Tensor:
+    x = torch.arange(ks, device=device, dtype=dtype) - ks // 2
+    if ks % 2 == 0:
+        x = x + 0.5
+    g = torch.exp(-x.pow(2.0) / (2.0 * sigma ** 2))
+    return g / g.sum()
+
+
+def kornia_resize(x: torch.Tensor, size, interpolation: str = "bicubic", align_corners: bool = True,
+                  antialias: bool = True) -> torch.Tensor:
+    """Restatement of `kornia.geometry.transform.resize` (kornia/geometry/transform/affwarp.py) for (B, C, H, W) input,
+    as `FrozenOpenCLIPImageEmbedderV2.preprocess` calls it (reference condition.py:322-326).  When downscaling with
+    antialias, kornia first blurs with a separable Gaussian -- sigma = (scale factor - 1) / 2 per axis (at least 0.001),
+    kernel size int(max(4 sigma, 3)) made odd, reflect border (kornia/filters/gaussian.py: gaussian_blur2d) -- and then
+    calls torch.nn.functional.interpolate WITHOUT torch's own antialias flag."""
+    h, w = x.shape[-2:]
+    factors = (h / size[0], w / size[1])
+    if antialias and max(factors) > 1:
+        sig = [max((f - 1.0) / 2.0, 0.001) for f in factors]
+        ks = [int(max(2.0 * 2 * s, 3)) for s in sig]
+        ks = [k + 1 if k % 2 == 0 else k for k in ks]
+        c = x.shape[1]
+        ky = _gaussian_kernel1d(ks[0], sig[0], x.device, x.dtype).view(1, 1, ks[0], 1).expand(c, 1, ks[0], 1)
+        kx = _gaussian_kernel1d(ks[1], sig[1], x.device, x.dtype).view(1, 1, 1, ks[1]).expand(c, 1, 1, ks[1])
+        x = F.pad(x, (ks[1] // 2, ks[1] // 2, ks[0] // 2, ks[0] // 2), mode="reflect")
+        x = F.conv2d(F.conv2d(x, kx, groups=c), ky, groups=c)
+    return F.interpolate(x, size=tuple(size), mode=interpolation, align_corners=align_corners)
 
 
 class AbstractEncoder(nn.Module):
@@ -53,12 +84,14 @@ class FrozenOpenCLIPEmbedder(AbstractEncoder):
             tok = torch.zeros((len(text), self.max_length), dtype=torch.long)
             tok[:, 0], tok[:, 1] = 49406, 49407
             return tok
-        try:
-            import open_clip
-        except Exception as e:
-            raise RuntimeError("tokenising strings needs the `open_clip` package (BPE vocabulary); pass an int64 "
-                               "(B, 77) token tensor instead") from e
-        return open_clip.tokenize(text)
+        if getattr(self, "_bpe", None) is None:
+            from .clip_tokenizer import CLIPTokenizer, default_vocab_path
+            vocab = default_vocab_path()
+            if vocab is None:
+                raise RuntimeError("tokenising strings needs CLIP's BPE merge table: set TC_CLIP_BPE_VOCAB to open_clip's "
+                                   "bpe_simple_vocab_16e6.txt.gz (or install open_clip), or pass an int64 (B, 77) token tensor")
+            self._bpe = CLIPTokenizer(vocab, context_length=self.max_length)
+        return self._bpe(text)
 
     def forward(self, text):
         tokens = text if torch.is_tensor(text) else self.tokenize(text)
@@ -94,7 +127,7 @@ class FrozenOpenCLIPImageEmbedderV2(AbstractEncoder):
 
     def preprocess(self, x):
         size = self.model.visual.grid_size[0] * self.model.visual.patch_size[0]
-        x = F.interpolate(x.float(), size=(size, size), mode="bicubic", align_corners=True, antialias=self.antialias)
+        x = kornia_resize(x.float(), (size, size), interpolation="bicubic", align_corners=True, antialias=self.antialias)
         x = (x + 1.) / 2.
         return (x - self.mean.view(1, 3, 1, 1)) / self.std.view(1, 3, 1, 1)
 
