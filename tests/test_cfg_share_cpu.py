@@ -76,3 +76,30 @@ def test_apply_model_multi_shares_only_identical_concat(tiny_sd, emu_backend):
             model.cfg_share = True
             scale = float(r_c.abs().max())
             assert torch.allclose(e_c, r_c, rtol=0, atol=2e-5 * scale) and torch.allclose(e_u, r_u, rtol=0, atol=2e-5 * scale)
+
+
+def test_decode_core_groups_by_row_count_not_bytes():
+    """decode_first_stage sends all B x T frames through one decoder call (the GEMM kernels address activations
+    block-relatively); it falls back to groups only when a launch's ROW count would leave int32."""
+    from tooncrafter_amd.lvdm.ddpm3d import LatentDiffusion
+
+    class Dec:
+        ch, calls = 128, []
+
+        def decode_clip(self, z, refs, scale=1.0):
+            self.calls.append((z.shape[0], None if refs is None else [r.shape[0] for r in refs]))
+            return torch.zeros(z.shape[0], 3, z.shape[2], 1, 1)                       # (the real one returns 8h x 8w frames)
+
+    class FS:
+        decoder = Dec()
+    m = LatentDiffusion.__new__(LatentDiffusion)
+    torch.nn.Module.__init__(m)
+    m.first_stage_model, m.scale_factor = FS(), 0.18215
+    z = torch.zeros(3, 4, 16, 40, 64)                                    # 3 clips: 8 GB of level-0 activations, 7.9 M rows
+    refs = [torch.zeros(3, 2, 8, 5, 5)]
+    out = m.decode_core(z, ref_context=refs)
+    assert out.shape == (3, 3, 16, 1, 1) and FS.decoder.calls == [(3, [3])]
+    Dec.calls.clear()
+    big = torch.zeros(1, 4, 16, 1280, 1024).expand(3, 4, 16, 1280, 1024)   # 1.3 G rows per clip: one clip per call
+    m.decode_core(big, ref_context=refs)
+    assert [c[0] for c in Dec.calls] == [1, 1, 1]
