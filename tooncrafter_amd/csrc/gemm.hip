@@ -423,6 +423,10 @@ extern "C" int tc_gemm_bf16(const TcGemmParams* pp, void* stream) {
     return TC_OK;
   }
   if (p.a_norm) return TC_ESHAPE;                                      // only the weight-stationary kernel normalises A rows
+  if (force == 0 && tc_gemm8_try(p, batch, s)) {                       // long-K / wide-N problems: 8-wave 256x256 ping-pong
+    TC_LAUNCH_CHECK();
+    return TC_OK;
+  }
   if (force == 0 && tc_gemm_tile16_try(p, batch, s)) {                 // widths 320 k at levels 0 / 1: 160x160 tiles
     TC_LAUNCH_CHECK();
     return TC_OK;

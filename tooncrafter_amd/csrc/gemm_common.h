@@ -263,3 +263,4 @@ inline bool tc_gemm_nmajor(const TcGemmParams& p) {
 int tc_gemm_wide_try(const TcGemmParams& p, int batch, hipStream_t s, bool force);   // gemm_wide.hip; 1 = launched
 int tc_gemm_tile16_try(const TcGemmParams& p, int batch, hipStream_t s);             // gemm16.hip; 1 = launched
 int tc_gemm_ws_try(const TcGemmParams& p, int batch, hipStream_t s);                 // gemm_ws.hip (K = 320); 1 = launched
+int tc_gemm8_try(const TcGemmParams& p, int batch, hipStream_t s);                   // gemm8.hip (8-wave 256x256 ping-pong); 1 = launched
