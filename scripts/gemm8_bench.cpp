@@ -63,7 +63,7 @@ static void* dev_f32(size_t n, float scale) {
 }
 
 struct Arm { const char* name; std::vector<std::pair<const char*, const char*>> env; };
-static const char* kSwitches[] = {"TC_GEMM8", "TC_GEMM_TILE", "TC_GEMM_TILE16", "TC_GEMM_WIDE", "TC_GEMM_WS", "TC_GEMM_SPLITK", "TC_GEMM_PIPE", "TC_G8_ABLATE", "TC_G8_STAGGER", "TC_G8_GRID"};
+static const char* kSwitches[] = {"TC_GEMM8", "TC_GEMM_TILE", "TC_GEMM_TILE16", "TC_GEMM_WIDE", "TC_GEMM_WS", "TC_GEMM_SPLITK", "TC_GEMM_PIPE", "TC_G8_ABLATE", "TC_G8_STAGGER", "TC_G8_GRID", "TC_GEMM_AP", "TC_AP_GRID"};
 static void set_env(const Arm& a) {
   for (const char* s : kSwitches) unsetenv(s);
   for (auto& kv : a.env) setenv(kv.first, kv.second, 1);
@@ -115,8 +115,8 @@ int main(int argc, char** argv) {
       {"three K-tiles 256x256x192", 256, 256, 192, 0, 0, 0, 0, false, true, false},
   };
   std::vector<Arm> arms = {
-      {"default(ref)", {{"TC_GEMM8", "0"}}},
-      {"gemm8", {{"TC_GEMM8", "2"}}},
+      {"default(ref)", {{"TC_GEMM8", "0"}, {"TC_GEMM_AP", "0"}}},
+      {"gemm8", {{"TC_GEMM8", "2"}, {"TC_GEMM_AP", "0"}}},
   };
   if (argc > 2 && !strcmp(argv[2], "stg")) {     // de-phasing sweep
     arms.push_back({"stg1", {{"TC_GEMM8", "2"}, {"TC_G8_STAGGER", "1"}}});

@@ -53,3 +53,19 @@ def nchw_flat_from_rows(rows: torch.Tensor, frames: int, h: int, w: int) -> torc
 
 UNET_CFG = FULL_UNET_CFG
 DD_CFG = FULL_DD_CFG
+
+
+# ---- first-stage encoder (row f1): tests/golden/make_encoder_fullsize_golden.py records the REAL reference on these frames
+ENC_GOLDEN_FILE = os.path.join(GOLDEN, "encoder_fullsize.npz")
+ENC_FRAMES, ENC_H, ENC_W = 16, 320, 512
+N_ENC = 65536                      # sampled positions per recorded tensor
+ENC_SEEDS = dict(mean=31, logvar=32, hid0=40, hid1=41, hid2=42, hid3=43, hid4=44)
+
+
+def encoder_frames():
+    """16 distinct frames in [-1, 1] (seed only): smooth structure + texture, so every level sees signal."""
+    g = torch.Generator().manual_seed(4242)
+    base = torch.randn(ENC_FRAMES, 3, ENC_H // 8, ENC_W // 8, generator=g)
+    img = torch.nn.functional.interpolate(base, size=(ENC_H, ENC_W), mode="bilinear", align_corners=False)
+    img = img + 0.25 * torch.randn(ENC_FRAMES, 3, ENC_H, ENC_W, generator=g)
+    return torch.tanh(img)

@@ -25,7 +25,7 @@ import pytest
 import torch
 
 import fullsize_cases as fc
-from conftest import rel_l2
+from conftest import ROOT, rel_l2
 from tooncrafter_amd import ops, synth
 
 pytestmark = pytest.mark.gpu
@@ -191,6 +191,39 @@ def test_decoder_full_size_vs_oracle(full_model, golden, inp, tag):
     assert torch.isfinite(y).all() and tuple(y.shape) == (1, 3, z.shape[2], 320, 512)
     assert e_out <= DEC_REL and abs(norm_ratio - 1.0) < 5e-3
     assert all(e_st[n] <= 1.5 * DEC_STAGE_FLOOR[n] for n in fc.PROBES), e_st
+
+
+# First-stage encoder at the full size (row f1; the reference call is scripts/evaluation/inference.py:164-178 ->
+# lvdm/models/autoencoder.py:100-110 -> lvdm/modules/networks/ae_modules.py:432-475).  The golden holds the REAL
+# reference's fp32 values at sampled positions (tests/golden/make_encoder_fullsize_golden.py; the oracle reproduces
+# them exactly, profiles/r04_encoder_fullsize_golden_vs_reference.txt).  Bounds: the bf16 path's distance measured on the
+# MI355X (profiles/r04_encoder_fullsize_parity.txt) x 1.5.
+ENC_BOUND = dict(mean=2.0e-2, logvar=2.0e-2, hid0=8e-3, hid1=1.2e-2, hid2=1.5e-2, hid3=1.8e-2, hid4=6e-3)
+
+
+@pytest.mark.timeout(900)
+def test_encoder_full_size_vs_reference_golden(full_model):
+    g = np.load(fc.ENC_GOLDEN_FILE)
+    x = fc.encoder_frames().to(DEV)
+    with torch.no_grad():
+        post, hidden = full_model.first_stage_model.encode(x, return_hidden_states=True)
+    got = dict(mean=post.mean, logvar=post.logvar, **{f"hid{i}": h for i, h in enumerate(hidden)})
+    errs = {}
+    for name, t in got.items():
+        assert tuple(t.shape) == tuple(g[name + "_shape"]), (name, t.shape)
+        flat = t.float().reshape(-1)
+        idx = fc.sample_idx(flat.numel(), fc.N_ENC, fc.ENC_SEEDS[name]).to(DEV)
+        errs[name] = rel_l2(flat[idx].cpu(), torch.from_numpy(g[name]))
+        nr = float(t.double().norm()) / float(g[name + "_norm"])
+        assert abs(nr - 1.0) < 1e-2, (name, nr)
+    text = "first-stage encoder 16 x 3 x 320 x 512, HIP path vs the real reference (fp32 CPU) at 65536 sampled positions: " + \
+        ", ".join(f"{k} {v:.3e}" for k, v in errs.items())
+    print(text)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "encoder_fullsize_parity.txt"), "w") as f:
+        f.write(text + "\n")
+    assert all(torch.isfinite(t).all() for t in got.values())
+    assert all(errs[k] <= ENC_BOUND[k] for k in errs), errs
 
 
 # MXFP8 GEMM path (BASELINE.json configs[4]): its OWN parity bounds.  The kernels are exact against the MX
