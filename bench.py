@@ -417,11 +417,46 @@ def run_clips_batched_decode(model, sampler, inps, ddim_steps):
     return video
 
 
+def rank_evidence(device, rank, local, world, clip_u8, gather_buf):
+    """What a reader of the JSON line can check about the N-rank run without trusting it: every rank reports the GPU
+    it really ran on (UUID / PCI address from the driver, host name) and a checksum of the LAST clip it produced; rank 0
+    recomputes the checksums from the buffers the RCCL gather filled and times one more gather by itself.  All of it
+    after the timed region.  At N = 1 the same keys are filled from the single rank (no collective)."""
+    import socket
+    props = torch.cuda.get_device_properties(device)
+    me = {"rank": rank, "local_rank": local, "host": socket.gethostname(), "name": props.name,
+          "uuid": str(getattr(props, "uuid", "")),
+          "pci": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0)),
+          "clip_checksum": int(clip_u8.to(torch.int64).sum().item())}
+    if world == 1:
+        return {"ranks_seen": 1, "devices": [me], "gather_verified": None, "gather_ms": None}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, me)
+    from tooncrafter_amd import dist as tcdist
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    tcdist.gather_clips(clip_u8, dst=0, out=gather_buf)
+    torch.cuda.synchronize()
+    gather_ms = (time.perf_counter() - t0) * 1e3
+    if rank != 0:
+        return {}
+    seen = [int(b.to(torch.int64).sum().item()) for b in gather_buf]
+    return {"ranks_seen": len({(d["host"], d["uuid"] or d["pci"]) for d in everyone}), "devices": everyone,
+            "gather_verified": seen == [d["clip_checksum"] for d in everyone],
+            "gather_ms": round(gather_ms, 3), "gather_bytes_per_rank": int(clip_u8.numel())}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` outside torchrun: start the N ranks ourselves, one process per GPU over
     RCCL on 127.0.0.1 (the analogue of the reference's scripts/evaluation/ddp_wrapper.py:29-47)."""
     import socket
     import subprocess
+    have = torch.cuda.device_count()
+    if have < args.gpus and not args.launcher_selftest:
+        # fail LOUDLY before any rendezvous: N ranks on fewer than N devices would otherwise sit in RCCL's init timeout
+        sys.stderr.write(f"bench.py --gpus {args.gpus}: this box exposes {have} GPU(s); refusing to start {args.gpus} ranks\n")
+        return 2
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -510,6 +545,8 @@ def main():
 
     from tooncrafter_amd import dist as tcdist
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if local >= torch.cuda.device_count():
+        sys.exit(f"bench.py: LOCAL_RANK={local} but this box exposes {torch.cuda.device_count()} GPU(s) -- one process per GPU")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     rank, world = tcdist.init(backend="nccl", device=device)
@@ -534,6 +571,7 @@ def main():
     gather_buf = [torch.empty(shape, device=device, dtype=torch.uint8) for _ in range(world)] \
         if rank == 0 and world > 1 else None
     counter = [0]
+    last_u8 = [None]
 
     def step():
         k = counter[0] % 2
@@ -544,6 +582,7 @@ def main():
             else:
                 video = run_clip(model, sampler, inps[k], args.ddim_steps)
             frames_u8 = tcout.clip_to_uint8(video)                       # (b, T, H, W, 3) uint8, on the device
+            last_u8[0] = frames_u8
             tcdist.gather_clips(frames_u8, dst=0, out=gather_buf)       # the one collective of the path
         return video
 
@@ -570,6 +609,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     finite = bool(torch.isfinite(video).all())
+    evidence = rank_evidence(device, rank, local, world, last_u8[0], gather_buf)
 
     result = None
     if rank == 0:
@@ -593,6 +633,7 @@ def main():
             "mfma_fraction_whole_clip": round(TFLOP_CLIP * args.steps * clips_per_step / dt / PEAK_BF16_TFLOPS, 4)
             if args.ddim_steps == 50 else None,
             "output_finite": finite,
+            **evidence,
         }
         if args.fp8:
             result["fp8_gemm_calls"] = dict(ops.backend().fp8_calls)

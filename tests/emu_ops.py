@@ -24,7 +24,10 @@ class EmuOps:
 
     def __init__(self, round_bf16=True, ln_fusion_k=None):
         self.round = round_bf16
-        self.ln_fusion_k = ln_fusion_k       # tests only: accept a_norm_eps for this K (the HIP library: K = 320, M >= 8192)
+        self.ln_fusion_k = ln_fusion_k       # tests only: accept a_norm_eps for EVERY consumer with this K.  The HIP library's
+                                             # default rule (csrc/gemm_ws.hip: ws_shape_ok, mode 1) is narrower: K = 320, N = 320,
+                                             # no GEGLU, M >= 65536 -- only the level-0 projections; TC_GEMM_WS=2 widens it to the
+                                             # qkv / GEGLU consumers (tests/test_gpu_gemm_ws.py runs those)
         self.ln_fused_calls = 0
 
     def gemm_ln_eligible(self, m, n, k, *, geglu=False, lda=None):

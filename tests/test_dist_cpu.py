@@ -93,3 +93,18 @@ def test_gather_world2_gloo():
         assert p.exitcode == 0
     assert all(ok for ok, _ in res)
     assert sorted(i for _, m in res for i in m) == list(range(5))
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus 2` on a box with fewer than 2 GPUs must fail at once and say why -- not start ranks that
+    sit in the collective-init timeout (here: 0 GPUs)."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-300:])
+    assert "refusing to start 2 ranks" in r.stderr
+    assert time.time() - t0 < 120

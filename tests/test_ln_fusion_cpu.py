@@ -59,3 +59,46 @@ def test_block_with_and_without_ln_fusion_agree():
     rel = lambda a, b: float((a - b).norm() / b.norm())
     print("LN fusion on/off: spatial", rel(ys1, ys0), "temporal", rel(yt1, yt0))
     assert rel(ys1, ys0) < 1e-2 and rel(yt1, yt0) < 1e-2      # bf16 rounding of w * gamma vs of gamma * x_hat
+
+
+def test_folded_weights_follow_a_reload_of_the_child_or_of_the_norm():
+    """the folded consumer weights are built from the CHILD's parameters (attn.to_q/k/v, ff.net[0].proj) and the
+    block's norm; reloading either alone must rebuild them (the block-level cache kept using the old ones)."""
+    blk = _make_block(None)
+    emu = EmuOps(round_bf16=True, ln_fusion_k=320)
+    prev = ops.set_backend(emu)
+    try:
+        b, t, h, w = 1, 4, 2, 3
+        x = torch.randn(b * t * h * w, 320, generator=torch.Generator().manual_seed(1)).to(torch.bfloat16)
+        act = Act(x, b, t, h, w)
+        with torch.no_grad():
+            y0 = blk.forward_temporal(x, act).float()
+            sd = {k: v.clone() * 0.5 for k, v in blk.ff.state_dict().items()}
+            blk.ff.load_state_dict(sd)                          # the child alone
+            y1 = blk.forward_temporal(x, act).float()
+            fresh = _make_block(None)
+            fresh.ff.load_state_dict(sd)
+            y1_ref = fresh.forward_temporal(x, act).float()
+            blk.norm3.load_state_dict({"weight": blk.norm3.weight * 2.0, "bias": blk.norm3.bias + 0.3})   # the norm alone
+            fresh.norm3.load_state_dict(blk.norm3.state_dict())
+            y2, y2_ref = blk.forward_temporal(x, act).float(), fresh.forward_temporal(x, act).float()
+    finally:
+        ops.set_backend(prev)
+    assert not torch.equal(y0, y1)
+    assert torch.equal(y1, y1_ref), "stale folded GEGLU weights after reloading ff alone"
+    assert torch.equal(y2, y2_ref), "stale folded weights after reloading the norm alone"
+
+
+def test_context_cache_is_stale_after_new_weights():
+    """cached K/V were projected with the weights of their epoch; load_state_dict bumps the epoch and the cache
+    must refresh although the conditioning tensor object is unchanged."""
+    from tooncrafter_amd.lvdm.common import PackedModule
+    ctx_t = torch.randn(1, 77 + 16 * 4, 96, generator=torch.Generator().manual_seed(2))
+    cache = ContextCache(ctx_t, 4)
+    assert cache.is_current(ctx_t)
+    blk = _make_block(96)
+    blk.load_state_dict(blk.state_dict())                       # any reload: the epoch moves on
+    assert cache.epoch != PackedModule.graph_epoch()
+    assert not cache.is_current(ctx_t)
+    cache.refresh(ctx_t)
+    assert cache.is_current(ctx_t)

@@ -284,6 +284,9 @@ int ws_mode() {            // TC_GEMM_WS = 0 never | 1 heuristic (default) | 2 w
 // Would the weight-stationary kernel take this (validated) problem?  One definition for the launcher and for the host
 // layer that decides whether a LayerNorm may be folded into its consumer (tc_gemm_ws_eligible).
 static bool ws_shape_ok(const TcGemmParams& p, int batch, int mode) {
+  // TC_GEMM_TILE forces a tile family: tc_gemm_bf16 then never comes here, so the host must not be told that a
+  // LayerNorm may be folded into this launch (the two rules disagreed under forced-tile sweeps)
+  if (const char* e = getenv("TC_GEMM_TILE")) { if (e[0]) return false; }
   if (mode == 0 || batch != 1 || p.gather != TC_GATHER_LINEAR || p.k != WS_K || p.lda < WS_K) return false;
   if (p.row_bias || p.alpha != 1.f || p.out_scale != 1.f || p.out_f32) return false;
   const bool geglu = p.act == TC_ACT_GEGLU;

@@ -55,11 +55,12 @@ class ContextCache:
             self.img_rows = torch.empty((b * li, cc), dtype=torch.bfloat16, device=context.device)
         self.kv = {}          # id(module) -> (module, kv_text, kv_img)
         self.key = None
+        self.epoch = -1       # PackedModule.graph_epoch() the K/V were projected under (new weights = stale K/V)
         self.refresh(context)
 
     def is_current(self, context: torch.Tensor) -> bool:
         """True when the cache was filled from this very tensor object at its current version."""
-        return self.key is not None and self.key.same([context])
+        return self.key is not None and self.epoch == PackedModule.graph_epoch() and self.key.same([context])
 
     def invalidate(self):
         self.key = None
@@ -77,6 +78,7 @@ class ContextCache:
         for module, kv_text, kv_img in self.kv.values():
             module.project_context(self, kv_text, kv_img)
         self.key = SourceKey([context])
+        self.epoch = PackedModule.graph_epoch()
 
 
 class GEGLU(nn.Module):
@@ -238,22 +240,27 @@ class BasicTransformerBlock(PackedModule):
 
     def _folded(self, i, kind):
         """Consumer weights of norm<i> with the LayerNorm's affine half folded in (common.fold_layernorm), packed like
-        the plain ones; built on first use, dropped with the rest of the packed tensors."""
-        pk = self.pk
-        key = f"ln{i}"
-        if key not in pk:
-            norm = getattr(self, f"norm{i}")
+        the plain ones.  Cached in the CONSUMER's packed dict (attn.pk / ff.pk), so reloading that child alone drops
+        them with the rest of its packed tensors, and stamped with the norm's parameter versions, so reloading the
+        norm alone rebuilds them (the block-level cache saw neither)."""
+        norm = getattr(self, f"norm{i}")
+        child = self.ff if kind == "ff" else (self.attn1 if i == 1 else self.attn2)
+        cpk = child.pk
+        key = f"ln_fold_{kind}"
+        stamp = (id(norm.weight), norm.weight._version, id(norm.bias), norm.bias._version)
+        ent = cpk.get(key)
+        if ent is None or ent[0] != stamp:
             with torch.no_grad():
                 if kind == "ff":
                     w, b = fold_layernorm(self.ff.net[0].proj.weight, self.ff.net[0].proj.bias, norm.weight, norm.bias)
-                    pk[key] = pack_geglu(w, b)
+                    folded = pack_geglu(w, b)
                 else:
-                    attn = self.attn1 if i == 1 else self.attn2
-                    raw = torch.cat([attn.to_q.weight, attn.to_k.weight, attn.to_v.weight], 0) if kind == "qkv" \
-                        else attn.to_q.weight
+                    raw = torch.cat([child.to_q.weight, child.to_k.weight, child.to_v.weight], 0) if kind == "qkv" \
+                        else child.to_q.weight
                     w, b = fold_layernorm(raw, None, norm.weight, norm.bias)
-                    pk[key] = (pack_linear(w), b)
-        return (*pk[key], self.LN_EPS)
+                    folded = (pack_linear(w), b)
+            ent = cpk[key] = (stamp, folded)
+        return (*ent[1], self.LN_EPS)
 
     def _pre(self, x, i, consumer, kind):
         """Input of the GEMM behind norm<i>: (LayerNorm(x), None), or -- when that GEMM can normalise its A rows itself

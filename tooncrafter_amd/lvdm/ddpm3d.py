@@ -317,6 +317,11 @@ class LatentDiffusion(DDPM):
         # exceed 2 GiB (level 0 of two 320x512 clips: 2.7 GB); what stays 32-bit is the ROW count of a launch.
         b, _, t, h, w = z.shape
         bmax = max(1, int(0x7fffffff // max(t * (8 * h) * (8 * w), 1)))
+        be = ops.backend()
+        if getattr(be, "fp8", None) is not None and getattr(be, "fp8_decoder", False):
+            # the MXFP8 GEMM still addresses A from the tensor base (csrc/gemm_mx.hip): with TC_FP8_DECODER=1 no
+            # activation may exceed the 31-bit byte range -- the widest one is 128 channels at full resolution
+            bmax = max(1, min(bmax, int(0x7fffff00 // max(t * (8 * h) * (8 * w) * 128 * 2, 1))))
         if b <= bmax:
             return dec.decode_clip(z, ref_context, scale=scale)
         outs = []
