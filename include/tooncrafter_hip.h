@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TC_ABI_VERSION 8
+#define TC_ABI_VERSION 9
 
 enum {
   TC_OK = 0,
@@ -203,6 +203,14 @@ int tc_concat_rows(const tc_bf16* a, int32_t ca, const tc_bf16* b, int32_t cb, t
 /* Sinusoidal embedding [cos | sin] (utils_diffusion.py:19-23) -> bf16 [n, dim_pad], then optional SiLU elementwise helper. */
 int tc_timestep_embedding(const float* t, tc_bf16* out, int32_t n, int32_t dim, int32_t ld, void* stream);
 int tc_silu_f32_to_bf16(const float* x, tc_bf16* y, int64_t n, void* stream);
+/* ABI 9 -- the same from the int64 timesteps the samplers hand over (ddim.py:166 `torch.full(..., dtype=torch.long)`,
+ * openaimodel3d.py:567-575): the `.to(float32)` in front of the embedding is a launch of its own otherwise. */
+int tc_timestep_embedding_i64(const int64_t* t, tc_bf16* out, int32_t n, int32_t dim, int32_t ld, void* stream);
+
+/* ABI 9 -- dst[k * rows + r, :] = src[r, :] for k < n (rows of row_bytes bytes, a multiple of 16; both contiguous):
+ * where batched guidance leaves the shared prefix (lvdm/common.py: CfgShare; the reference runs the n passes as n
+ * separate UNet calls, ddim.py:226-233) the single-copy rows and embedding are repeated n-fold. */
+int tc_repeat_rows(const void* src, void* dst, int64_t rows, int32_t row_bytes, int32_t n, void* stream);
 
 /* AE3DConv tail (autoencoder_dualref.py:929-935): Conv3d 3->3 (3,1,1) over T on the fp32
  * [B*T*HW, ld] rows produced by the 128->3 conv, written as (B, 3, T, H, W) fp32. */

@@ -206,6 +206,9 @@ class EmuOps:
     def silu_to_bf16(self, x):
         return F.silu(x).to(BF16)
 
+    def repeat_rows(self, x, n):
+        return x.repeat(n, 1)
+
     def time_mix3(self, rows, w, bias, *, b, t, h, w_):
         x = rows[:, :3].reshape(b, t, h, w_, 3).permute(0, 4, 1, 2, 3)
         return F.conv3d(x, w.reshape(3, 3, 3, 1, 1), bias, padding=(1, 0, 0)).contiguous()

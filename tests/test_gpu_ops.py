@@ -330,6 +330,16 @@ def test_embedding_helpers(hip, emu):
     check(hip.timestep_embedding(t, 320, 320), emu.timestep_embedding(t, 320, 320), "timestep_embedding")
     x = rnd(4, 1280, seed=52, dtype=torch.float32)
     check(hip.silu_to_bf16(x), emu.silu_to_bf16(x), "silu_to_bf16")
+    ti = torch.tensor([999, 19, 0, 10, 601], device=DEV, dtype=torch.int64)        # ABI 9: the samplers' int64 timesteps
+    assert torch.equal(hip.timestep_embedding(ti, 320, 320), hip.timestep_embedding(ti.to(torch.float32), 320, 320))
+
+
+@pytest.mark.parametrize("rows,c,n,dtype", [(1, 8, 2, BF16), (2560, 320, 2, BF16), (777, 328, 3, BF16), (2, 4700, 3, torch.float32)])
+def test_repeat_rows(hip, rows, c, n, dtype):
+    """ABI 9: x.repeat(n, 1) on 16-byte rows (the shared prefix of batched guidance leaving its single copy)."""
+    x = rnd(rows, c, seed=57, dtype=dtype)
+    out = hip.repeat_rows(x, n)
+    assert out.shape == (n * rows, c) and torch.equal(out, x.repeat(n, 1))
 
 
 def test_time_mix3(hip, emu):

@@ -108,6 +108,29 @@ __global__ void timestep_embedding_kernel(const float* __restrict__ t, bf16_t* _
   out[i] = (bf16_t)v;
 }
 
+__global__ void timestep_embedding_i64_kernel(const int64_t* __restrict__ t, bf16_t* __restrict__ out, int n, int dim, int ld) {
+  const int half = dim / 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * ld) return;
+  const int r = i / ld, col = i - r * ld;
+  float v = 0.f;
+  if (col < 2 * half) {
+    const int j = col < half ? col : col - half;
+    const float freq = expf(-9.210340371976184f * (float)j / (float)half);   // ln(10000)
+    const float arg = (float)t[r] * freq;                                    // == t.to(float32) first, then the fp32 product
+    v = col < half ? cosf(arg) : sinf(arg);
+  }
+  out[i] = (bf16_t)v;
+}
+
+// dst[k * rows + r] = src[r] in 16-byte vectors: each source vector is read once and written n times
+__global__ __launch_bounds__(256) void repeat_rows_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, int64_t vecs, int n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < vecs; i += (int64_t)gridDim.x * blockDim.x) {
+    const u32x4 v = src[i];
+    for (int k = 0; k < n; ++k) dst[(int64_t)k * vecs + i] = v;
+  }
+}
+
 __global__ void silu_f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     y[i] = (bf16_t)silu_f(x[i]);
@@ -294,6 +317,25 @@ extern "C" int tc_timestep_embedding(const float* t, tc_bf16* out, int32_t n, in
   const int total = n * ld;
   hipLaunchKernelGGL(timestep_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), t, reinterpret_cast<bf16_t*>(out), n, dim, ld);
+  TC_LAUNCH_CHECK();
+  return TC_OK;
+}
+
+extern "C" int tc_timestep_embedding_i64(const int64_t* t, tc_bf16* out, int32_t n, int32_t dim, int32_t ld, void* stream) {
+  if (!t || !out || n <= 0 || dim <= 0 || ld < dim) return TC_EINVAL;
+  const int total = n * ld;
+  hipLaunchKernelGGL(timestep_embedding_i64_kernel, dim3((total + 255) / 256), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), t, reinterpret_cast<bf16_t*>(out), n, dim, ld);
+  TC_LAUNCH_CHECK();
+  return TC_OK;
+}
+
+extern "C" int tc_repeat_rows(const void* src, void* dst, int64_t rows, int32_t row_bytes, int32_t n, void* stream) {
+  if (!src || !dst || rows <= 0 || row_bytes <= 0 || n <= 0) return TC_EINVAL;
+  if ((row_bytes & 15) || !tc_aligned16(src) || !tc_aligned16(dst)) return TC_EALIGN;
+  const int64_t vecs = rows * (row_bytes >> 4);
+  hipLaunchKernelGGL(repeat_rows_kernel, dim3(grid_for(vecs, 256, 4096)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const u32x4*>(src), reinterpret_cast<u32x4*>(dst), vecs, n);
   TC_LAUNCH_CHECK();
   return TC_OK;
 }

@@ -279,7 +279,7 @@ class BasicTransformerBlock(PackedModule):
         h, ln = self._pre(x, 1, self.attn1.pk["wqkv"], "qkv")
         x = self.attn1.forward_spatial_self(h, x, act, ln=ln)
         if share is not None:
-            x, act = x.repeat(share.n, 1), share.expand(act)
+            x, act = ops.repeat_rows(x, share.n), share.expand(act)
             share.done = True
         h, ln = self._pre(x, 2, self.attn2.pk["wq"], "q")
         x = self.attn2.forward_cross(h, x, act, ctx, ln=ln)

@@ -8,6 +8,8 @@ from dataclasses import dataclass
 import torch
 import torch.nn as nn
 
+from .. import ops
+
 BF16 = torch.bfloat16
 
 
@@ -49,13 +51,13 @@ class CfgShare:
     paths part.  Exact (the identical copies were bit-identical to begin with: no cross-sample term anywhere)."""
 
     def __init__(self, n: int, emb1: torch.Tensor):
-        self.n, self.emb1, self.embn, self.done = n, emb1, emb1.repeat(n, 1), False
+        self.n, self.emb1, self.embn, self.done = n, emb1, ops.repeat_rows(emb1, n), False
 
     def emb(self) -> torch.Tensor:
         return self.embn if self.done else self.emb1
 
     def expand(self, act: "Act") -> "Act":
-        return Act(act.rows.repeat(self.n, 1), act.b * self.n, act.t, act.h, act.w)
+        return Act(ops.repeat_rows(act.rows, self.n), act.b * self.n, act.t, act.h, act.w)
 
 
 class SourceKey:

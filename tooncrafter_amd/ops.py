@@ -439,13 +439,23 @@ class HipOps:
         return out
 
     def timestep_embedding(self, t, dim, ld=None):
-        """t: fp32 [n] -> bf16 [n, ld] = [cos | sin | 0 pad]."""
-        if t.dtype != torch.float32 or t.dim() != 1 or not t.is_cuda:
-            raise ValueError("timestep_embedding: fp32 CUDA [n]")
+        """t: fp32 or int64 [n] -> bf16 [n, ld] = [cos | sin | 0 pad] (int64: converted to fp32 in the kernel, like the
+        reference's `timesteps[:, None].float()`, utils_diffusion.py:19-23)."""
+        if t.dtype not in (torch.float32, torch.int64) or t.dim() != 1 or not t.is_cuda or not t.is_contiguous():
+            raise ValueError("timestep_embedding: contiguous fp32 / int64 CUDA [n]")
         ld = dim if ld is None else ld
         out = torch.empty((t.shape[0], ld), dtype=BF16, device=t.device)
-        _lib.check(self.lib.tc_timestep_embedding(t.data_ptr(), out.data_ptr(), t.shape[0], dim, ld, _stream()),
-                   "tc_timestep_embedding")
+        fn = self.lib.tc_timestep_embedding if t.dtype == torch.float32 else self.lib.tc_timestep_embedding_i64
+        _lib.check(fn(t.data_ptr(), out.data_ptr(), t.shape[0], dim, ld, _stream()), "tc_timestep_embedding")
+        return out
+
+    def repeat_rows(self, x, n):
+        """[rows, C] -> [n * rows, C]: n copies one after the other (x.repeat(n, 1) as one launch of this library)."""
+        if x.dim() != 2 or not x.is_cuda or not x.is_contiguous() or (x.shape[1] * x.element_size()) % 16:
+            raise ValueError("repeat_rows: contiguous CUDA [rows, C] with 16-byte rows")
+        out = torch.empty((n * x.shape[0], x.shape[1]), dtype=x.dtype, device=x.device)
+        _lib.check(self.lib.tc_repeat_rows(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1] * x.element_size(), n, _stream()),
+                   "tc_repeat_rows")
         return out
 
     def silu_to_bf16(self, x):
