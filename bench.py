@@ -161,12 +161,13 @@ class GemmProbe:
         def gemm(a, w, bias=None, **kw):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            out = self.orig(a, w, bias, **kw)
+            res = self.orig(a, w, bias, **kw)
             e1.record()
+            out = res[0] if isinstance(res, tuple) else res          # gn_stats=True: (out, partial GroupNorm sums)
             conv = kw.get("conv")
             m = out.shape[0] if conv is None and kw.get("m") is None else (kw.get("m") or out.shape[0])
             self.rec.append((e0, e1, 2.0 * m * w.shape[0] * w.shape[1] * kw.get("batch", 1)))
-            return out
+            return res
         self.b.gemm = gemm
         return self
 

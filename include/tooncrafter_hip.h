@@ -92,6 +92,13 @@ typedef struct TcGemmParams {
    * accepts can carry it (whole rows of A must sit in one block); tc_gemm_bf16 returns TC_ESHAPE otherwise. */
   int32_t a_norm;
   float a_norm_eps;
+  /* ABI 9 -- GroupNorm statistics from the producer (lvdm/basics.py:76-87 normalises what openaimodel3d.py:154,179,
+   * 255-266 just wrote): not NULL = besides C the launch emits, for every block of tc_gemm_gn_rows() consecutive output
+   * rows and every output column, the sum and the sum of squares of the bf16-ROUNDED outputs, fp32
+   * [ceil(m / gn_rows)][2][n], summed in a fixed order (no atomics).  tc_groupnorm_part turns them into (mean, rstd) --
+   * the consumer's own statistics pass over the tensor (one of GroupNorm's two reads) disappears.  Only for problems
+   * whose tc_gemm_gn_rows() is non-zero; tc_gemm_bf16 returns TC_ESHAPE otherwise. */
+  float* gn_part;
 } TcGemmParams;
 
 /* C = epilogue(gather(A) * W^T), bf16 MFMA, fp32 accumulate.
@@ -106,6 +113,10 @@ int64_t tc_gemm_workspace(const TcGemmParams* p);
 /* ABI 8 -- 1 if tc_gemm_bf16 would run this problem on the weight-stationary K = 320 kernel (csrc/gemm_ws.hip), the
  * only one that accepts a_norm = 1: the host asks BEFORE it decides to drop a LayerNorm launch. */
 int tc_gemm_ws_eligible(const TcGemmParams* p);
+/* ABI 9 -- row-block height of TcGemmParams.gn_part for this problem under the current routing (160: the 160x160-tile
+ * kernel; 128: the 128x128-tile kernel without split-K), or 0 when the kernel that would run it cannot emit
+ * statistics (the caller then leaves gn_part NULL and the consumer computes its own). */
+int tc_gemm_gn_rows(const TcGemmParams* p);
 
 /* ABI 7 -- MX block-scaled fp8 GEMM (BASELINE.json configs[4]: the CDNA4 fp8 MFMA GEMM path).
  * Operands are OCP MX "MXFP8": e4m3 elements with one E8M0 (power-of-two) scale per 32 consecutive K
@@ -174,6 +185,12 @@ int64_t tc_groupnorm_workspace(int32_t samples, int32_t rows, int32_t c);
 int tc_groupnorm(const tc_bf16* x, tc_bf16* y, const float* gamma, const float* beta,
                  int32_t samples, int32_t rows, int32_t c, float eps, int32_t silu,
                  void* workspace, int64_t workspace_bytes, void* stream);
+/* ABI 9 -- the same with the statistics taken from a producer's partial sums (TcGemmParams.gn_part:
+ * [samples * rows / part_rows][2][c] fp32; rows % part_rows == 0): a reduction over the partials (fp64, fixed order)
+ * and ONE pass over x.  workspace: tc_groupnorm_workspace() bytes. */
+int tc_groupnorm_part(const tc_bf16* x, tc_bf16* y, const float* gamma, const float* beta, const float* part,
+                      int32_t part_rows, int32_t samples, int32_t rows, int32_t c, float eps, int32_t silu,
+                      void* workspace, int64_t workspace_bytes, void* stream);
 
 /* LayerNorm over the last axis of [rows, C] (attention.py:225-227), eps 1e-5, affine. */
 int tc_layernorm(const tc_bf16* x, tc_bf16* y, const float* gamma, const float* beta,

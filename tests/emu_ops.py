@@ -22,13 +22,15 @@ def _f(t):
 class EmuOps:
     name = "emu"
 
-    def __init__(self, round_bf16=True, ln_fusion_k=None):
+    def __init__(self, round_bf16=True, ln_fusion_k=None, gn_rows=0):
         self.round = round_bf16
         self.ln_fusion_k = ln_fusion_k       # tests only: accept a_norm_eps for EVERY consumer with this K.  The HIP library's
                                              # default rule (csrc/gemm_ws.hip: ws_shape_ok, mode 1) is narrower: K = 320, N = 320,
                                              # no GEGLU, M >= 65536 -- only the level-0 projections; TC_GEMM_WS=2 widens it to the
                                              # qkv / GEGLU consumers (tests/test_gpu_gemm_ws.py runs those)
         self.ln_fused_calls = 0
+        self.gn_rows = gn_rows               # tests only: row-block height of the emulated producer statistics (0 = none)
+        self.gn_part_made = self.gn_part_used = 0
 
     def gemm_ln_eligible(self, m, n, k, *, geglu=False, lda=None):
         return self.ln_fusion_k is not None and k == self.ln_fusion_k
@@ -64,7 +66,21 @@ class EmuOps:
 
     def gemm(self, a, w, bias=None, *, act=ACT_NONE, residual=None, row_bias=None, row_div=0, alpha=1.0,
              out_scale=1.0, out=None, out_f32=False, conv=None, batch=1, stride_a=0, stride_w=0, stride_c=0,
-             m=None, a_norm_eps=None):
+             m=None, a_norm_eps=None, gn_stats=False):
+        if gn_stats:
+            # ABI 9: the producer's partial GroupNorm sums, per block of `gn_rows` rows (tests: 160, like the 160-tile kernel)
+            res = self.gemm(a, w, bias, act=act, residual=residual, row_bias=row_bias, row_div=row_div, alpha=alpha,
+                            out_scale=out_scale, out=out, out_f32=out_f32, conv=conv, batch=batch, stride_a=stride_a,
+                            stride_w=stride_w, stride_c=stride_c, m=m, a_norm_eps=a_norm_eps)
+            if self.gn_rows <= 0 or act == ACT_GEGLU or out_f32 or not res.is_contiguous():
+                return res, None
+            from tooncrafter_amd.ops import GnPart
+            r = self.gn_rows
+            x = _f(res)
+            nb = (x.shape[0] + r - 1) // r
+            xp = F.pad(x, (0, 0, 0, nb * r - x.shape[0])).reshape(nb, r, x.shape[1])
+            self.gn_part_made += 1
+            return res, GnPart(torch.stack([xp.sum(1), (xp * xp).sum(1)], 1).contiguous(), r, res)
         n, k = w.shape
         if batch > 1:
             assert conv is None and residual is None and row_bias is None
@@ -152,8 +168,23 @@ class EmuOps:
         return self._out(o.permute(0, 3, 1, 2, 4).reshape(b * t * hw, c)).contiguous()
 
     # ------------------------------------------------------------------ norms
-    def groupnorm(self, x, gamma, beta, *, samples, rows, eps, silu=False):
+    def groupnorm(self, x, gamma, beta, *, samples, rows, eps, silu=False, part=None):
         c = x.shape[1]
+        if part is not None and part.of is x and rows % part.rows == 0 and part.sums.shape[2] == c \
+                and part.sums.shape[0] * part.rows == samples * rows:
+            # statistics from the producer's partial sums, as tc_groupnorm_part takes them (fp64 E[x^2] - mean^2)
+            self.gn_part_used += 1
+            cpg = c // 32
+            sums = part.sums.double().reshape(samples, rows // part.rows, 2, 32, cpg).sum(dim=(1, 4))    # [samples, 2, 32]
+            cnt = rows * cpg
+            mean = sums[:, 0] / cnt
+            var = (sums[:, 1] / cnt - mean * mean).clamp_min(0.0)
+            xf = _f(x).reshape(samples, rows, 32, cpg)
+            y = (xf - mean.float()[:, None, :, None]) * (1.0 / torch.sqrt(var + eps)).float()[:, None, :, None]
+            y = y.reshape(samples, rows, c) * gamma + beta
+            if silu:
+                y = F.silu(y)
+            return self._out(y.reshape(samples * rows, c)).contiguous()
         xf = _f(x).reshape(samples, rows, c).permute(0, 2, 1)
         y = F.group_norm(xf, 32, gamma, beta, eps)
         if silu:

@@ -70,7 +70,7 @@ def test_unet_tiny_vs_reference_golden(hip, tiny_unet):
     print(f"tiny UNet: vs reference golden {e_ref:.3e}; vs emulated contract {e_emu:.3e}; "
           f"emulated contract vs golden {rel_l2(y_emu.cpu(), ref):.3e}")
     assert torch.isfinite(y).all()
-    assert e_ref < 3e-2 and e_emu < 3e-2
+    assert e_ref < 3.5e-2 and e_emu < 3.5e-2        # 1.5 x the measured 2.31e-2 / 2.28e-2 (profiles/r04_tiny_model_parity.txt)
 
 
 def test_unet_deterministic_and_batch_consistent(hip, tiny_unet):
@@ -104,7 +104,7 @@ def test_decoder_tiny_vs_reference_golden(hip, tiny_decoder):
     e_ref, e_emu = rel_l2(out.cpu(), ref), rel_l2(out.cpu(), out_emu.cpu())
     print(f"tiny decoder: vs reference golden {e_ref:.3e}; vs emulated contract {e_emu:.3e}")
     assert out.shape == ref.shape and torch.isfinite(out).all()
-    assert e_ref < 3e-2 and e_emu < 3e-2
+    assert e_ref < 2.0e-2 and e_emu < 2.0e-2        # 1.5 x the measured 1.34e-2 / 1.33e-2
 
 
 def test_decoder_14_frame_second_pass(hip, tiny_decoder, tiny_sd):
@@ -124,7 +124,7 @@ def test_decoder_14_frame_second_pass(hip, tiny_decoder, tiny_sd):
         rb = odec.decode_first_stage(dsd, z2, refs_cpu)
     ea, eb = rel_l2(a.cpu(), ra), rel_l2(b.cpu(), rb)
     print(f"decoder T=5 vs oracle {ea:.3e}; T=3 (cached refs) vs oracle {eb:.3e}")
-    assert ea < 3e-2 and eb < 3e-2
+    assert ea < 2.4e-2 and eb < 2.0e-2              # 1.5 x the measured 1.60e-2 / 1.31e-2
 
 
 def _tiny_pipeline(tiny_sd):
@@ -167,7 +167,7 @@ def test_ddim_tiny_trajectory_vs_reference_golden(hip, tiny_sd):
     final = rel_l2(out.cpu(), torch.from_numpy(g["samples"]))
     print("DDIM-5 tiny trajectory vs reference: pred_x0 rel-L2 per step", [f"{e:.3e}" for e in errs], f"final {final:.3e}")
     assert torch.isfinite(out).all()
-    assert max(errs) < 0.15 and final < 0.15
+    assert max(errs) < 0.133 and final < 0.108      # 1.5 x the measured 8.84e-2 (worst step) / 7.17e-2
 
 
 def test_ddim_multicond_tiny_trajectory_vs_reference_golden(hip, tiny_sd):
@@ -206,7 +206,7 @@ def test_ddim_multicond_tiny_trajectory_vs_reference_golden(hip, tiny_sd):
     print("multi-cond DDIM-4 tiny trajectory vs reference: pred_x0 rel-L2 per step", [f"{e:.3e}" for e in errs],
           f"final {final:.3e}")
     assert torch.isfinite(out).all()
-    assert max(errs) < 0.15 and final < 0.15
+    assert max(errs) < 0.165 and final < 0.099      # 1.5 x the measured 1.10e-1 (worst step) / 6.59e-2
 
 
 def test_unet_hipgraph_replay_matches_eager(hip, tiny_unet):
@@ -261,7 +261,7 @@ def test_unet_full_size_vs_contract(hip, manifest):
     e = rel_l2(y.cpu(), y_emu.cpu())
     print(f"full-size UNet (B=2): HIP vs emulated contract rel-L2 {e:.3e}; out std {float(y.std()):.3f}")
     assert torch.isfinite(y).all()
-    assert e < 3e-2
+    assert e < 2.6e-2                                # 1.5 x the measured 1.70e-2
 
 
 def test_encoder_tiny_vs_reference_golden(hip, tiny_sd):
@@ -277,7 +277,7 @@ def test_encoder_tiny_vs_reference_golden(hip, tiny_sd):
     errs = [rel_l2(h.cpu(), torch.from_numpy(g[f"hid{i}"])) for i, h in enumerate(hidden)]
     ez = rel_l2(z.cpu(), torch.from_numpy(g["z"]))
     print(f"tiny encoder: z rel-L2 {ez:.3e}; hidden states", [f"{e:.3e}" for e in errs])
-    assert ez < 3e-2 and max(errs) < 3e-2
+    assert ez < 3.3e-3 and max(errs) < 1.85e-2      # 1.5 x the measured 2.17e-3 / 1.23e-2
 
 
 def test_resampler_vs_reference_golden_and_full_size_oracle(hip):

@@ -35,6 +35,7 @@ class TcGemmParams(C.Structure):
         ("stride_a", C.c_int64), ("stride_w", C.c_int64), ("stride_c", C.c_int64),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("a_norm", C.c_int32), ("a_norm_eps", C.c_float),
+        ("gn_part", C.c_void_p),
     ]
 
 
@@ -101,6 +102,9 @@ SYMBOLS = {
     "tc_ddim_workspace": (C.c_int64, [C.c_int32]),
     "tc_ddim_step": (C.c_int, [C.POINTER(TcDdimParams), C.c_void_p, C.c_int64, C.c_void_p]),
     "tc_gemm_ws_eligible": (C.c_int, [C.POINTER(TcGemmParams)]),
+    "tc_gemm_gn_rows": (C.c_int, [C.POINTER(TcGemmParams)]),
+    "tc_groupnorm_part": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "tc_abi_version": (C.c_int, []),
     "tc_build_info": (C.c_char_p, []),
 }

@@ -275,6 +275,40 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TcGemmParams pin, co
     if (p.alpha == 1.f && p.out_scale == 1.f) epilogue_fast<true, BM, BN, true>(p, cs, tid, tile_m, tile_n, bz, pre);
     else epilogue_fast<true, BM, BN, false>(p, cs, tid, tile_m, tile_n, bz, pre);
   }
+  else if (TM == 2 && TN == 2 && pin.gn_part && splits == 1) {
+    // GroupNorm statistics of this 128 x 128 tile (ABI 9): per-thread sums over its 8 rows -> lanes of equal column
+    // group (lane, lane ^ 16, lane ^ 32) -> the four waves through LDS, in wave order (no atomics: bit-reproducible)
+    EpiStats st;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { st.s[e] = 0.f; st.q[e] = 0.f; }
+    epilogue_fast<false, BM, BN, false, true>(p, cs, tid, tile_m, tile_n, bz, pre, &st);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      st.s[e] += __shfl_xor(st.s[e], 16, 64); st.s[e] += __shfl_xor(st.s[e], 32, 64);
+      st.q[e] += __shfl_xor(st.q[e], 16, 64); st.q[e] += __shfl_xor(st.q[e], 32, 64);
+    }
+    __syncthreads();                                // every thread is done with the fp32 tile
+    float* red = reinterpret_cast<float*>(smem);    // [wave][2][BN]
+    if (lane < 16) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(wave * 2 + 0) * BN + lane * 8 + e] = st.s[e];
+        red[(wave * 2 + 1) * BN + lane * 8 + e] = st.q[e];
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const int n = tile_n * BN + tid;
+      if (n < p.n) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { a += red[(w * 2 + 0) * BN + tid]; b += red[(w * 2 + 1) * BN + tid]; }
+        float* o = pin.gn_part + (int64_t)tile_m * 2 * p.n + n;
+        o[0] = a;
+        o[p.n] = b;
+      }
+    }
+  }
   else if (p.alpha == 1.f && p.out_scale == 1.f && p.act == TC_ACT_NONE && !p.row_bias)
     epilogue_fast<false, BM, BN, true>(p, cs, tid, tile_m, tile_n, bz, pre);
   else epilogue_fast<false, BM, BN, false>(p, cs, tid, tile_m, tile_n, bz, pre);
@@ -364,6 +398,25 @@ static void tc_gemm_pick_tile(int m, int n, int batch, bool geglu, int* tm, int*
   }
 }
 
+// ABI 9: row-block height of gn_part under the routing tc_gemm_bf16 would take (same order of the same questions)
+extern "C" int tc_gemm_gn_rows(const TcGemmParams* pp) {
+  if (!pp) return 0;
+  const TcGemmParams& p = *pp;
+  const int batch = p.batch > 0 ? p.batch : 1;
+  if (batch != 1 || p.act == TC_ACT_GEGLU || p.out_f32 || (p.n & 7) != 0 || p.a_norm || p.m <= 0 || p.n <= 0 || p.k <= 0) return 0;
+  if (getenv("TC_GEMM_TILE") && getenv("TC_GEMM_TILE")[0]) return 0;          // forced tile families: tuning runs only
+  if (const char* e = getenv("TC_GN_PART")) { if (e[0] == '0') return 0; }    // A/B switch: never emit
+  if (tc_gemm_ws_try(p, batch, nullptr, true)) return 0;
+  if (tc_gemm8_try(p, batch, nullptr, true)) return 0;
+  if (tc_gemm_tile16_try(p, batch, nullptr, true)) return 160;
+  if (tc_gemm_wide_try(p, batch, nullptr, false, true)) return 0;
+  if (p.workspace && tc_gemm_splits(p) > 1 &&
+      p.workspace_bytes >= (int64_t)tc_gemm_splits(p) * p.m * p.n * (int64_t)sizeof(float)) return 0;
+  int tm, tn;
+  tc_gemm_pick_tile(p.m, p.n, batch, false, &tm, &tn);
+  return (tm == 2 && tn == 2) ? 128 : 0;
+}
+
 extern "C" int tc_gemm_bf16(const TcGemmParams* pp, void* stream) {
   if (!pp) return TC_EINVAL;
   const TcGemmParams& p = *pp;
@@ -407,6 +460,7 @@ extern "C" int tc_gemm_bf16(const TcGemmParams* pp, void* stream) {
     return TC_EINVAL;
   }
   if (!tc_gemm_offsets_fit(p)) return TC_ESHAPE;          // buffer-load offsets are 31-bit
+  if (p.gn_part && tc_gemm_gn_rows(&p) == 0) return TC_ESHAPE;          // the kernel of this problem emits no statistics
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // TC_GEMM_TILE = wide | 22 | 21 | 12 | 11 forces one tile family (tuning / A-B runs); default: heuristic
   const int force = [] {                                   // per call (scripts/gemm_autotune.py sweeps it in one process)

@@ -32,7 +32,12 @@ constexpr int T16_NT = T16_WT / 16;                          // 5 MFMA tiles per
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 // PIPE: two K-steps of tile loads in flight, counted vmcnt + raw barriers (see gemm.hip)
-template <int GATHER, bool PIPE>
+// STATS (ABI 9, TcGemmParams.gn_part): the epilogue also emits, per output column, the sum and the sum of squares of
+// the tile's 160 rows of bf16-rounded outputs.  Vector v = lane + 64 q of a 16-row pass is (row v / 10, column group
+// v % 10) in EVERY pass, so a lane keeps one accumulator set per q (3 x 16 registers) and the walk of the plain
+// epilogue stays as it is (a first version pinned lanes to column groups -- 60 active lanes, three row steps per pass --
+// and cost the convolutions more than GroupNorm saved: +0.4 ms per forward against -0.3 ms).
+template <int GATHER, bool PIPE, bool STATS>
 __global__ __launch_bounds__(256, 2) void gemm16_kernel(const TcGemmParams p, const int order) {
   __shared__ __attribute__((aligned(1024))) char smem[2 * T16_STAGE];
 
@@ -153,6 +158,11 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(const TcGemmParams p, co
   char* c_base = reinterpret_cast<char*>(p.c) + bz * p.stride_c * (p.out_f32 ? 4 : 2);
   const int col_w0 = tile_n * T16_BN + wn * T16_WT;
   constexpr int VPR = T16_WT / 8;                      // 10 vectors of 8 columns per slab row
+  float gs[3][8], gq[3][8];                            // STATS: column sums of vector slot lane + 64 q over the five passes
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { gs[q][e] = 0.f; gq[q][e] = 0.f; }
   auto epi_pass = [&](auto I_) {
     constexpr int i = decltype(I_)::value;
     // C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg
@@ -199,7 +209,14 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(const TcGemmParams p, co
           *reinterpret_cast<f32x4*>(op) = f32x4{x[0], x[1], x[2], x[3]};
           *reinterpret_cast<f32x4*>(op + 4) = f32x4{x[4], x[5], x[6], x[7]};
         } else {
-          *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(c_base) + (int64_t)m * p.ldc + n0) = pack8(x);
+          const u32x4 packed = pack8(x);
+          *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(c_base) + (int64_t)m * p.ldc + n0) = packed;
+          if (STATS) {
+            float fr[8];
+            unpack8(packed, fr);                     // what GroupNorm will read back: the rounded values
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { gs[q][e] += fr[e]; gq[q][e] += fr[e] * fr[e]; }
+          }
         }
       }
     }
@@ -210,6 +227,38 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(const TcGemmParams p, co
   epi_pass(integral_constant<int, 2>{});
   epi_pass(integral_constant<int, 3>{});
   epi_pass(integral_constant<int, 4>{});
+  if (STATS) {
+    // fold: 16 vector slots (rows of a pass) x 2 waves (wm) per column, through LDS in a fixed order (no atomics).
+    // Each wave parks its 160 slots x 16 floats in a 10 KiB region of the (now idle) stage buffers.
+    __syncthreads();                                   // every wave is done with its epilogue slab
+    float* mine = reinterpret_cast<float*>(smem) + wave * (160 * 16);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int v = lane + 64 * q;
+      if (v < 16 * VPR) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { mine[v * 16 + e] = gs[q][e]; mine[v * 16 + 8 + e] = gq[q][e]; }
+      }
+    }
+    __syncthreads();
+    if (tid < T16_BN) {
+      const int n = tile_n * T16_BN + tid;
+      if (n < p.n) {
+        const int wnn = tid / T16_WT, cw = tid - wnn * T16_WT;       // wave column, column inside the wave tile
+        const int vc = cw >> 3, e = cw & 7;
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int wmm = 0; wmm < 2; ++wmm) {
+          const float* sl = reinterpret_cast<const float*>(smem) + (wmm * 2 + wnn) * (160 * 16);
+#pragma unroll
+          for (int lr = 0; lr < 16; ++lr) { a += sl[(lr * VPR + vc) * 16 + e]; b += sl[(lr * VPR + vc) * 16 + 8 + e]; }
+        }
+        float* o = p.gn_part + (int64_t)tile_m * 2 * p.n + n;
+        o[0] = a;
+        o[p.n] = b;
+      }
+    }
+  }
 }
 
 int tile16_mode() {        // TC_GEMM_TILE16 = 0 never | 1 heuristic (default) | 2 whenever the shape allows
@@ -220,7 +269,7 @@ int tile16_mode() {        // TC_GEMM_TILE16 = 0 never | 1 heuristic (default) |
 }  // namespace
 
 // Decide whether the 160x160 kernel should take this (already validated) GEMM, and launch it.  1 = launched.
-int tc_gemm_tile16_try(const TcGemmParams& p, int batch, hipStream_t s) {
+int tc_gemm_tile16_try(const TcGemmParams& p, int batch, hipStream_t s, bool dry) {
   const int mode = tile16_mode();
   if (mode == 0 || p.act == TC_ACT_GEGLU || (p.n % T16_BN) != 0) return 0;
   const int tiles_n = p.n / T16_BN;
@@ -242,15 +291,18 @@ int tc_gemm_tile16_try(const TcGemmParams& p, int batch, hipStream_t s) {
   }
   const int64_t nblk = (int64_t)tiles_n * 8 * ((tiles_m + 7) / 8);
   if (nblk > 0x7fffffffLL) return 0;
+  if (dry) return 1;
   dim3 grid((unsigned)nblk, 1, (unsigned)batch), block(256);
   const int order = tc_gemm_tile_order(p, tiles_n);
+  const bool stats = p.gn_part != nullptr;
   // TC_GEMM_PIPE = 2 only: on this tile the deeper prefetch measured 0.97-1.02x (profiles/r03_pipe_bench.txt) -- two
   // blocks of 80 KiB per CU already overlap each other's load latency -- so the default keeps the plain loop
   const bool pipe = [] { const char* e = getenv("TC_GEMM_PIPE"); return e && e[0] == '2'; }();      // per call (A/B runs)
 #define TC_LAUNCH16(G)                                                                              \
   do {                                                                                              \
-    if (pipe) hipLaunchKernelGGL((gemm16_kernel<G, true>), grid, block, 0, s, p, order);            \
-    else hipLaunchKernelGGL((gemm16_kernel<G, false>), grid, block, 0, s, p, order);                \
+    if (stats) hipLaunchKernelGGL((gemm16_kernel<G, false, true>), grid, block, 0, s, p, order);    \
+    else if (pipe) hipLaunchKernelGGL((gemm16_kernel<G, true, false>), grid, block, 0, s, p, order); \
+    else hipLaunchKernelGGL((gemm16_kernel<G, false, false>), grid, block, 0, s, p, order);         \
   } while (0)
   switch (p.gather) {
     case TC_GATHER_LINEAR: TC_LAUNCH16(TC_GATHER_LINEAR); break;

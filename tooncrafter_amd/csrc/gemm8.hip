@@ -461,7 +461,7 @@ int g8_mode() {        // TC_GEMM8 = 0 never | 1 heuristic (default) | 2 wheneve
 }  // namespace
 
 // Decide whether the 8-wave kernel should take this (already validated) GEMM, and launch it.  1 = launched.
-int tc_gemm8_try(const TcGemmParams& p, int batch, hipStream_t s) {
+int tc_gemm8_try(const TcGemmParams& p, int batch, hipStream_t s, bool dry) {
   const int mode = g8_mode();
   if (mode == 0) return 0;
   const bool geglu = p.act == TC_ACT_GEGLU;
@@ -485,12 +485,15 @@ int tc_gemm8_try(const TcGemmParams& p, int batch, hipStream_t s) {
     // with matrix work when a CU holds a single block).  The heuristic takes the first class only.
     const int64_t tiles = (int64_t)tiles_n * tiles_m * batch;
     const double n_eff = (double)p.n / ((double)tiles_n * G8_BN);
-    const bool one_round = tiles >= 224 && tiles <= 256;
+    // (one round: linear layers only -- the convolutions of that size are on the 160x160-tile kernel, which the 8-wave
+    // kernel does NOT beat: level-1 3x3 640 -> 640 0.85x, 1920 -> 640 0.80x)
+    const bool one_round = tiles >= 224 && tiles <= 256 && p.gather == TC_GATHER_LINEAR;
     const bool many = tiles >= 1024 && p.n % G8_BN == 0;
     if (geglu || p.k < 2048 || n_eff < 0.8 || !(one_round || many)) return 0;
   }
   const int64_t total = (int64_t)tiles_n * tiles_m;
   if (total > 0x7fffffffLL) return 0;
+  if (dry) return 1;
   static const int cus = [] { int d = 0, n = 256; if (hipGetDevice(&d) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
   const int gmax = [&] { const char* e = getenv("TC_G8_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : cus; }() & ~7;
   const int g = (int)(total < gmax ? total : gmax);         // a multiple of 8 unless it covers every tile in one round

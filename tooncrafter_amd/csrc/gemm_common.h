@@ -260,7 +260,8 @@ inline bool tc_gemm_nmajor(const TcGemmParams& p) {
   return p.m <= 2048 && tc_w_extent(p) > tc_a_extent(p);
 }
 
-int tc_gemm_wide_try(const TcGemmParams& p, int batch, hipStream_t s, bool force);   // gemm_wide.hip; 1 = launched
-int tc_gemm_tile16_try(const TcGemmParams& p, int batch, hipStream_t s);             // gemm16.hip; 1 = launched
-int tc_gemm_ws_try(const TcGemmParams& p, int batch, hipStream_t s);                 // gemm_ws.hip (K = 320); 1 = launched
-int tc_gemm8_try(const TcGemmParams& p, int batch, hipStream_t s);                   // gemm8.hip (8-wave 256x256 ping-pong); 1 = launched
+// (dry = true: the routing decision only, nothing is launched -- tc_gemm_gn_rows asks every family in tc_gemm_bf16's order)
+int tc_gemm_wide_try(const TcGemmParams& p, int batch, hipStream_t s, bool force, bool dry = false);   // gemm_wide.hip; 1 = launched
+int tc_gemm_tile16_try(const TcGemmParams& p, int batch, hipStream_t s, bool dry = false);   // gemm16.hip; 1 = launched
+int tc_gemm_ws_try(const TcGemmParams& p, int batch, hipStream_t s, bool dry = false);       // gemm_ws.hip (K = 320); 1 = launched
+int tc_gemm8_try(const TcGemmParams& p, int batch, hipStream_t s, bool dry = false);         // gemm8.hip (8-wave 256x256 ping-pong); 1 = launched

@@ -15,6 +15,12 @@ struct EpiGeo {
   static constexpr int ROWS_PER_IT = 256 / GROUPS;
 };
 
+// GroupNorm statistics of the tile (ABI 9, TcGemmParams.gn_part): per thread the sum and the sum of squares of the
+// bf16-ROUNDED outputs of its 8 columns over its rows of the tile; gemm.hip folds them over the tile's rows
+struct EpiStats {
+  float s[8], q[8];
+};
+
 struct EpiPrefetch {
   float bv[8], bg[8];       // bias of this thread's 8 output columns (GEGLU: values | gates)
   u32x4 rres[8];            // residual vectors of its rows (non-GEGLU tiles of at most 128 x 128 / 256 threads)
@@ -73,9 +79,9 @@ __device__ __forceinline__ void epi_load_residual(const TcGemmParams& p, int tid
 // with K as short as 320 the epilogue is a third of a block's instructions, so it gets its own
 // straight-line instance without the per-element multiplies and activation selects.
 // `pre`: bias already loaded by epi_load_bias; residual loaded by epi_load_residual if pre.have_res.
-template <bool GEGLU, int BM, int BN, bool PLAIN>
+template <bool GEGLU, int BM, int BN, bool PLAIN, bool STATS = false>
 __device__ __forceinline__ void epilogue_fast(const TcGemmParams& p, const float* cs, int tid, int tile_m, int tile_n,
-                                              int64_t bz, EpiPrefetch& pre) {
+                                              int64_t bz, EpiPrefetch& pre, EpiStats* st = nullptr) {
   using G = EpiGeo<GEGLU, BM, BN>;
   constexpr int GROUPS = G::GROUPS, ITERS = G::ITERS, ROWS_PER_IT = G::ROWS_PER_IT;
   const int g = tid % GROUPS;
@@ -158,7 +164,14 @@ __device__ __forceinline__ void epilogue_fast(const TcGemmParams& p, const float
         *reinterpret_cast<f32x4*>(op) = f32x4{x[0], x[1], x[2], x[3]};
         *reinterpret_cast<f32x4*>(op + 4) = f32x4{x[4], x[5], x[6], x[7]};
       } else {
-        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(c_base) + (int64_t)m * p.ldc + n0) = pack8(x);
+        const u32x4 packed = pack8(x);
+        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(c_base) + (int64_t)m * p.ldc + n0) = packed;
+        if (STATS) {
+          float fr[8];
+          unpack8(packed, fr);                     // what GroupNorm will read back: the rounded values
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { st->s[e] += fr[e]; st->q[e] += fr[e] * fr[e]; }
+        }
       }
     }
   }

@@ -311,7 +311,7 @@ int wide_enabled() {        // TC_GEMM_WIDE=0: never (read per call: A/B runs fl
 }  // namespace
 
 // Decide whether the wide kernel should take this (already validated) GEMM, and launch it.
-int tc_gemm_wide_try(const TcGemmParams& p, int batch, hipStream_t s, bool force) {
+int tc_gemm_wide_try(const TcGemmParams& p, int batch, hipStream_t s, bool force, bool dry) {
   if (!wide_enabled()) return 0;
   const bool geglu = p.act == TC_ACT_GEGLU;
   const int n_out = geglu ? p.n / 2 : p.n;
@@ -340,6 +340,7 @@ int tc_gemm_wide_try(const TcGemmParams& p, int batch, hipStream_t s, bool force
   }
   const int64_t nblk = (int64_t)tiles_n * 8 * ((tiles_m + 7) / 8);
   if (nblk > 0x7fffffffLL) return 0;
+  if (dry) return 1;
   dim3 grid((unsigned)nblk, 1, (unsigned)batch);
   if (tnw == 5) launch_wide<5>(p, grid, s);
   else if (tnw == 4) launch_wide<4>(p, grid, s);

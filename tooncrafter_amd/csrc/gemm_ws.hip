@@ -309,9 +309,10 @@ extern "C" int tc_gemm_ws_eligible(const TcGemmParams* p) {
 }
 
 // 1 = launched
-int tc_gemm_ws_try(const TcGemmParams& p, int batch, hipStream_t s) {
+int tc_gemm_ws_try(const TcGemmParams& p, int batch, hipStream_t s, bool dry) {
   const int mode = ws_mode();
   if (!ws_shape_ok(p, batch, mode)) return 0;
+  if (dry) return 1;
   const bool geglu = p.act == TC_ACT_GEGLU;
   const int slabs = p.n / (geglu ? 256 : 320);
   const int ntiles = (p.m + WS_ROWS - 1) / WS_ROWS;

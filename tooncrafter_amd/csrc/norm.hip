@@ -157,6 +157,40 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   }
 }
 
+// ABI 9: (mean, rstd) from a PRODUCER's partial sums (TcGemmParams.gn_part: per block of `prows` rows and per channel
+// the sum and the sum of squares of the values it stored): part [blocks][2][c] -> stats [samples][32][2].  One 256-thread
+// block per (sample, group): thread t takes row blocks t, t + 256, ... and walks the group's cpg contiguous channels
+// (clip-wide norms have only 2 x 32 (sample, group) pairs but 256 row blocks each: a wave per pair -- the first version --
+// spent 40 dependent round trips there and made the whole operator SLOWER than the two-pass one); fp64, fixed order.
+__global__ __launch_bounds__(256) void gn_finalize_part_kernel(const float* __restrict__ part, float* __restrict__ stats,
+                                                               int samples, int rows, int c, int prows, float eps) {
+  __shared__ double red[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sg = blockIdx.x;                                  // sample*32 + group
+  const int sample = sg >> 5, grp = sg & 31;
+  const int cpg = c / 32, nb = rows / prows;
+  const float* pp = part + ((int64_t)sample * nb * 2) * c + grp * cpg;
+  double a = 0.0, b = 0.0;
+  for (int blk = tid; blk < nb; blk += 256) {
+    const float* r0 = pp + (int64_t)blk * 2 * c;
+    for (int ch = 0; ch < cpg; ++ch) { a += r0[ch]; b += r0[c + ch]; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
+  if (lane == 0) { red[0][wave] = a; red[1][wave] = b; }
+  __syncthreads();
+  if (tid == 0) {
+    a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    b = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const double cnt = (double)rows * cpg;
+    const double mean = a / cnt;
+    double var = b / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[(int64_t)sg * 2] = (float)mean;
+    stats[(int64_t)sg * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               const float* __restrict__ stats, int rows, int c,
@@ -547,6 +581,27 @@ extern "C" int tc_groupnorm(const tc_bf16* x, tc_bf16* y, const float* gamma, co
                      eps);
   TC_LAUNCH_CHECK();
   hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, s, reinterpret_cast<const bf16_t*>(x),
+                     reinterpret_cast<bf16_t*>(y), gamma, beta, stats, rows, c, cr, silu);
+  TC_LAUNCH_CHECK();
+  return TC_OK;
+}
+
+extern "C" int tc_groupnorm_part(const tc_bf16* x, tc_bf16* y, const float* gamma, const float* beta, const float* part,
+                                 int32_t part_rows, int32_t samples, int32_t rows, int32_t c, float eps, int32_t silu,
+                                 void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!x || !y || !gamma || !beta || !part || !workspace || samples <= 0 || rows <= 0 || c <= 0 || part_rows <= 0) return TC_EINVAL;
+  if ((c % 32) != 0 || (c % 8) != 0 || c > GN_MAX_SLOTS * GN_THREADS * 8 || c > 4096 || samples > 65535) return TC_ESHAPE;
+  if ((rows % part_rows) != 0) return TC_ESHAPE;                 // a block of partial sums may not straddle two samples
+  if (!tc_aligned16(x) || !tc_aligned16(y)) return TC_EALIGN;
+  if (workspace_bytes < tc_groupnorm_workspace(samples, rows, c)) return TC_EWORKSPACE;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int nch, cr;
+  gn_chunking(samples, rows, &nch, &cr);
+  float* stats = reinterpret_cast<float*>(workspace) + (int64_t)samples * nch * 64;
+  hipLaunchKernelGGL(gn_finalize_part_kernel, dim3(samples * 32), dim3(256), 0, s, part, stats, samples, rows, c,
+                     part_rows, eps);
+  TC_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(nch, samples), dim3(GN_THREADS), 0, s, reinterpret_cast<const bf16_t*>(x),
                      reinterpret_cast<bf16_t*>(y), gamma, beta, stats, rows, c, cr, silu);
   TC_LAUNCH_CHECK();
   return TC_OK;

@@ -98,13 +98,19 @@ class TemporalConvBlock(PackedModule):
             pk[f"w{i}"], pk[f"cb{i}"] = pack_convt3(seq[-1].weight), f32(seq[-1].bias)
         return pk
 
-    def forward(self, act: Act) -> Act:
+    def forward(self, act: Act, part=None) -> Act:
+        """`part`: GroupNorm partial sums of act.rows from the GEMM that produced them (ops.GnPart) or None.  Every
+        convolution here feeds the next GroupNorm, so it is asked for the statistics of what it stores (ABI 9): the
+        norm then reads its input once instead of twice."""
         pk = self.pk
         y = act.rows
         geom = dict(kind="t3", frames=act.frames, t_len=act.t, cin=act.c, h_out=act.h, w_out=act.w)
         for i in range(1, 5):
-            y = ops.groupnorm(y, pk[f"g{i}"], pk[f"b{i}"], samples=act.b, rows=act.t * act.hw, eps=1e-5, silu=True)
-            y = ops.gemm(y, pk[f"w{i}"], pk[f"cb{i}"], conv=geom, residual=act.rows if i == 4 else None)
+            y = ops.groupnorm(y, pk[f"g{i}"], pk[f"b{i}"], samples=act.b, rows=act.t * act.hw, eps=1e-5, silu=True, part=part)
+            if i < 4:
+                y, part = ops.gemm(y, pk[f"w{i}"], pk[f"cb{i}"], conv=geom, gn_stats=True)
+            else:
+                y = ops.gemm(y, pk[f"w{i}"], pk[f"cb{i}"], conv=geom, residual=act.rows)
         return act.like(y)
 
 
@@ -147,16 +153,16 @@ class ResBlock(TimestepBlock, PackedModule):
         off, width = self.emb_slice
         geom1, _, _ = _conv_geom(act, ceil_to(act.c, 64))
         h = ops.groupnorm(act.rows, pk["g1"], pk["b1"], samples=act.frames, rows=act.hw, eps=1e-5, silu=True)
-        h = ops.gemm(h, pk["w1"], pk["cb1"], conv=geom1, row_bias=emb_all[:, off:off + width],
-                     row_div=act.t * act.hw)
-        h = ops.groupnorm(h, pk["g2"], pk["b2"], samples=act.frames, rows=act.hw, eps=1e-5, silu=True)
+        # both convolutions feed a GroupNorm (out_layers' / the temporal block's first): they emit its statistics (ABI 9)
+        h, part = ops.gemm(h, pk["w1"], pk["cb1"], conv=geom1, row_bias=emb_all[:, off:off + width],
+                           row_div=act.t * act.hw, gn_stats=True)
+        h = ops.groupnorm(h, pk["g2"], pk["b2"], samples=act.frames, rows=act.hw, eps=1e-5, silu=True, part=part)
         skip = act.rows if "ws" not in pk else ops.gemm(act.rows, pk["ws"], pk["bs"])
         geom2, _, _ = _conv_geom(act, self.out_channels)
-        h = ops.gemm(h, pk["w2"], pk["cb2"], conv=geom2, residual=skip)
-        out = act.like(h)
-        if self.use_temporal_conv:
-            out = self.temopral_conv(out)
-        return out
+        if not self.use_temporal_conv:
+            return act.like(ops.gemm(h, pk["w2"], pk["cb2"], conv=geom2, residual=skip))
+        h, part = ops.gemm(h, pk["w2"], pk["cb2"], conv=geom2, residual=skip, gn_stats=True)
+        return self.temopral_conv(act.like(h), part)
 
 
 class TimestepEmbedSequential(nn.Sequential, TimestepBlock):

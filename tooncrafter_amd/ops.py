@@ -70,6 +70,15 @@ class MxRows:
         self.device = q.device
 
 
+class GnPart:
+    """Partial GroupNorm sums a GEMM emitted beside its output (ABI 9): `sums` fp32 [row blocks, 2, N] (sum, sum of
+    squares of the rounded outputs per block of `rows` rows and per column), `of` the output tensor they describe."""
+    __slots__ = ("sums", "rows", "of")
+
+    def __init__(self, sums, rows, of):
+        self.sums, self.rows, self.of = sums, rows, of
+
+
 class HipOps:
     """The product backend: ctypes calls into libtooncrafter_hip.so."""
 
@@ -98,6 +107,11 @@ class HipOps:
         self._wq = {}
         # LayerNorm -> consumer GEMM fusion (ABI 8, gemm_ln_eligible); TC_FUSE_LN=0 keeps the separate launch (A/B runs)
         self.fuse_ln = os.environ.get("TC_FUSE_LN", "1") != "0"
+        # ABI 9: GroupNorm statistics from the producing GEMM.  OFF by default: measured end to end (profiles/
+        # r04_gn_part_ab.txt, same lease, alternating runs) GroupNorm loses 0.3-0.4 ms per guided forward (4.71 -> 4.39,
+        # 6.08 -> 5.72 on a slow lease) and the producing convolutions gain 0.4-1.1 ms (their epilogues fold 160 rows per
+        # column and end on two block barriers): 7.79 vs 7.79 frames/s on one lease, 6.63 vs 6.75 on the other
+        self.gn_part = os.environ.get("TC_GN_PART", "0") == "1"
 
     # ------------------------------------------------------------------ workspace
     def _workspace(self, nbytes: int, device) -> torch.Tensor:
@@ -107,8 +121,12 @@ class HipOps:
     # ------------------------------------------------------------------ GEMM family
     def gemm(self, a, w, bias=None, *, act=ACT_NONE, residual=None, row_bias=None, row_div=0,
              alpha=1.0, out_scale=1.0, out=None, out_f32=False, conv=None, batch=1,
-             stride_a=0, stride_w=0, stride_c=0, m=None, a_norm_eps=None):
+             stride_a=0, stride_w=0, stride_c=0, m=None, a_norm_eps=None, gn_stats=False):
         """out[M, N'] = act(alpha * gather(a) @ w^T + bias + row_bias[m // row_div]) * out_scale + residual.
+
+        gn_stats (ABI 9): the result is (out, GnPart | None) -- when the kernel this problem runs on can emit them
+        (tc_gemm_gn_rows), per-row-block column sums of the rounded outputs, which `groupnorm(..., part=)` takes instead
+        of reading the tensor once more for its statistics; None otherwise (the caller passes it on all the same).
 
         a_norm_eps (ABI 8): LayerNorm of the rows of `a` as a prologue of the product -- (x - mean) * rsqrt(var + eps)
         over the K columns; gamma / beta must already be folded into w / bias (lvdm.common.fold_layernorm).  Only for
@@ -195,7 +213,7 @@ class HipOps:
             if self._fp8_eligible(p, conv is not None, n_out, batch):
                 self.fp8_calls["mx"] += 1
                 self._gemm_mx(p, a, w, mx_a)
-                return out
+                return (out, None) if gn_stats else out
             if mx_a is not None:
                 raise ValueError("gemm: MXFP8 activation handed to a GEMM the fp8 route does not take")
             self.fp8_calls["bf16"] += 1
@@ -203,8 +221,14 @@ class HipOps:
         if nbytes > 0:
             ws = self._workspace(nbytes, a.device)
             p.workspace, p.workspace_bytes = ws.data_ptr(), nbytes
+        part = None
+        if gn_stats and self.gn_part and out.is_contiguous():
+            prow = self.lib.tc_gemm_gn_rows(C.byref(p))         # 160 / 128 / 0: the routing's own answer
+            if prow > 0:
+                part = GnPart(torch.empty(((mm + prow - 1) // prow, 2, n), dtype=torch.float32, device=a.device), prow, out)
+                p.gn_part = part.sums.data_ptr()
         _lib.check(self.lib.tc_gemm_bf16(C.byref(p), _stream()), "tc_gemm_bf16")
-        return out
+        return (out, part) if gn_stats else out
 
     def gemm_ln_eligible(self, m, n, k, *, geglu=False, lda=None) -> bool:
         """Would `gemm(a[m, k], w[n, k], act=GEGLU if geglu, a_norm_eps=...)` be accepted, i.e. may the caller drop the
@@ -344,8 +368,9 @@ class HipOps:
         return out
 
     # ------------------------------------------------------------------ norms
-    def groupnorm(self, x, gamma, beta, *, samples, rows, eps, silu=False):
-        """x: contiguous [samples*rows, C]; statistics over (rows, C/32) per (sample, group)."""
+    def groupnorm(self, x, gamma, beta, *, samples, rows, eps, silu=False, part=None):
+        """x: contiguous [samples*rows, C]; statistics over (rows, C/32) per (sample, group).  `part` (a GnPart from
+        the gemm that produced x, or None): statistics from the producer's partial sums -- one pass over x, not two."""
         x = _rows_view(x)
         c = x.shape[1]
         if not x.is_contiguous() or x.shape[0] != samples * rows:
@@ -356,6 +381,12 @@ class HipOps:
         y = torch.empty_like(x)
         nbytes = self.lib.tc_groupnorm_workspace(samples, rows, c)
         ws = self._workspace(nbytes, x.device)
+        if part is not None and part.of is x and rows % part.rows == 0 and part.sums.shape[2] == c \
+                and part.sums.shape[0] * part.rows == samples * rows:
+            _lib.check(self.lib.tc_groupnorm_part(x.data_ptr(), y.data_ptr(), gp, bp, part.sums.data_ptr(), part.rows, samples,
+                                                  rows, c, float(eps), 1 if silu else 0, ws.data_ptr(), nbytes, _stream()),
+                       "tc_groupnorm_part")
+            return y
         _lib.check(self.lib.tc_groupnorm(x.data_ptr(), y.data_ptr(), gp, bp, samples,
                                          rows, c, float(eps), 1 if silu else 0, ws.data_ptr(), nbytes, _stream()),
                    "tc_groupnorm")

@@ -55,11 +55,13 @@ class TorchLibOps(HipOps):
         self.t = load()
 
     def gemm(self, a, w, bias=None, *, act=ACT_NONE, residual=None, row_bias=None, row_div=0, alpha=1.0, out_scale=1.0,
-             out=None, out_f32=False, conv=None, batch=1, stride_a=0, stride_w=0, stride_c=0, m=None, a_norm_eps=None):
-        if out is not None or batch != 1 or m is not None or self.fp8 is not None:      # fp8 routing lives in HipOps.gemm
+             out=None, out_f32=False, conv=None, batch=1, stride_a=0, stride_w=0, stride_c=0, m=None, a_norm_eps=None,
+             gn_stats=False):
+        # fp8 routing and the ABI 9 producer statistics (a second result) live in HipOps.gemm
+        if out is not None or batch != 1 or m is not None or self.fp8 is not None or gn_stats:
             return super().gemm(a, w, bias, act=act, residual=residual, row_bias=row_bias, row_div=row_div, alpha=alpha,
                                 out_scale=out_scale, out=out, out_f32=out_f32, conv=conv, batch=batch, stride_a=stride_a,
-                                stride_w=stride_w, stride_c=stride_c, m=m, a_norm_eps=a_norm_eps)
+                                stride_w=stride_w, stride_c=stride_c, m=m, a_norm_eps=a_norm_eps, gn_stats=gn_stats)
         return self.t.gemm(a, w, bias, residual, row_bias, int(row_div), int(act), float(alpha), float(out_scale),
                            bool(out_f32), conv_list(conv), -1.0 if a_norm_eps is None else float(a_norm_eps))
 
@@ -77,7 +79,9 @@ class TorchLibOps(HipOps):
     def attention_temporal(self, qkv, *, b, t, hw, heads, scale=None):
         return self.t.attention_temporal(qkv, b, t, hw, heads, float(64 ** -0.5 if scale is None else scale))
 
-    def groupnorm(self, x, gamma, beta, *, samples, rows, eps, silu=False):
+    def groupnorm(self, x, gamma, beta, *, samples, rows, eps, silu=False, part=None):
+        if part is not None:
+            return super().groupnorm(x, gamma, beta, samples=samples, rows=rows, eps=eps, silu=silu, part=part)
         return self.t.groupnorm(x, gamma, beta, samples, rows, float(eps), bool(silu))
 
     def layernorm(self, x, gamma, beta, eps=1e-5, mx_for=None):
