@@ -488,7 +488,7 @@ int tc_gemm8_try(const TcGemmParams& p, int batch, hipStream_t s, bool dry) {
     // (one round: linear layers only -- the convolutions of that size are on the 160x160-tile kernel, which the 8-wave
     // kernel does NOT beat: level-1 3x3 640 -> 640 0.85x, 1920 -> 640 0.80x)
     const bool one_round = tiles >= 224 && tiles <= 256 && p.gather == TC_GATHER_LINEAR;
-    const bool many = tiles >= 1024 && p.n % G8_BN == 0;
+    const bool many = tiles >= 1024 && p.n % G8_BN == 0 && p.n >= 512 && p.k >= 4096;   // (256 -> 256 convolutions: 0.89-0.92x)
     if (geglu || p.k < 2048 || n_eff < 0.8 || !(one_round || many)) return 0;
   }
   const int64_t total = (int64_t)tiles_n * tiles_m;
