@@ -145,6 +145,24 @@ int tc_quant_mxfp8(const tc_bf16* x, int64_t rows, int32_t k, int32_t ld, uint8_
 int tc_layernorm_mxfp8(const tc_bf16* x, uint8_t* q, int32_t ldq, uint8_t* s, int32_t lds, const float* gamma,
                        const float* beta, int32_t rows, int32_t c, float eps, void* stream);
 
+/* ABI 9 -- the feed-forward of a level-0 transformer block as ONE launch (lvdm/modules/attention.py:415-442 behind
+ * norm3, attention.py:244-246):  out = x + w2 . GEGLU(w1 . LN(x) + b1) + b2.  The hidden tensor ([m, hidden] bf16: 210 MB
+ * at the BASELINE shape) never reaches HBM.  c = 320 and hidden = 1280 only (tc_ff_geglu_fused_eligible).
+ *   x    [m, ldx] bf16: the block's input rows -- LayerNorm input AND residual;
+ *   w1   [2*hidden, c] bf16 in tc_gemm_bf16's GEGLU packing (every 32 rows = 16 value rows, then their 16 gate rows):
+ *        the very tensor the TC_ACT_GEGLU projection takes; with ln != 0 the LayerNorm's gamma is folded in
+ *        (w1[n, :] *= gamma) and b1 carries w1 . beta, as for TcGemmParams.a_norm;
+ *   b1   [2*hidden] fp32, packed like w1's rows;   w2 [c, hidden] bf16;   b2 [c] fp32;   out [m, ldo] bf16;
+ *   ln   != 0: rows are normalised, (x - mean) * rsqrt(var + ln_eps) with fp32 statistics, before the first product;
+ *        0: x is taken as already normalised for the product (and still added as the residual). */
+typedef struct TcFfParams {
+  const tc_bf16* x; const tc_bf16* w1; const float* b1; const tc_bf16* w2; const float* b2; tc_bf16* out;
+  int32_t m, c, hidden, ldx, ldo, ln;
+  float ln_eps;
+} TcFfParams;
+int tc_ff_geglu_fused_eligible(const TcFfParams* p);
+int tc_ff_geglu_fused(const TcFfParams* p, void* stream);
+
 typedef struct TcAttnParams {
   const tc_bf16* q; const tc_bf16* k; const tc_bf16* v; tc_bf16* o;
   int32_t batch, heads, lq, lk;

@@ -22,8 +22,10 @@ def _f(t):
 class EmuOps:
     name = "emu"
 
-    def __init__(self, round_bf16=True, ln_fusion_k=None, gn_rows=0):
+    def __init__(self, round_bf16=True, ln_fusion_k=None, gn_rows=0, ff_fused_c=None):
         self.round = round_bf16
+        self.ff_fused_c = ff_fused_c         # tests only: width whose feed-forward takes the one-launch route (the library: 320)
+        self.ff_fused_calls = 0
         self.ln_fusion_k = ln_fusion_k       # tests only: accept a_norm_eps for EVERY consumer with this K.  The HIP library's
                                              # default rule (csrc/gemm_ws.hip: ws_shape_ok, mode 1) is narrower: K = 320, N = 320,
                                              # no GEGLU, M >= 65536 -- only the level-0 projections; TC_GEMM_WS=2 widens it to the
@@ -34,6 +36,16 @@ class EmuOps:
 
     def gemm_ln_eligible(self, m, n, k, *, geglu=False, lda=None):
         return self.ln_fusion_k is not None and k == self.ln_fusion_k
+
+    def ff_fused_eligible(self, m, c, hidden, *, ldx=None):
+        return self.ff_fused_c is not None and c == self.ff_fused_c and hidden == 4 * c
+
+    def ff_geglu_fused(self, x, w1, b1, w2, b2, *, ln_eps=None):
+        """csrc/ff_fused.hip: the same roundings as the three launches it replaces (normalised rows and hidden values in
+        bf16, fp32 sums), so the mirror IS the two emulated GEMMs."""
+        self.ff_fused_calls += 1
+        g = self.gemm(x, w1, b1, act=ACT_GEGLU, a_norm_eps=ln_eps) if ln_eps is not None else self.gemm(x, w1, b1, act=ACT_GEGLU)
+        return self.gemm(g, w2, b2, residual=x)
 
     def _out(self, x, f32=False):
         if f32:

@@ -30,7 +30,8 @@ def test_struct_layout_matches_header():
     with open(os.path.join(ROOT, "include", "tooncrafter_hip.h")) as f:
         header = f.read()
     for cname, ctype in (("TcGemmParams", _lib.TcGemmParams), ("TcAttnParams", _lib.TcAttnParams),
-                         ("TcDdimParams", _lib.TcDdimParams), ("TcGemmMxParams", _lib.TcGemmMxParams)):
+                         ("TcDdimParams", _lib.TcDdimParams), ("TcGemmMxParams", _lib.TcGemmMxParams),
+                         ("TcFfParams", _lib.TcFfParams)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), header, re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []

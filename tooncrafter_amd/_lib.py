@@ -69,6 +69,14 @@ class TcDdimParams(C.Structure):
 
 
 # name -> (restype, argtypes): every symbol include/tooncrafter_hip.h declares
+class TcFfParams(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p), ("out", C.c_void_p),
+        ("m", C.c_int32), ("c", C.c_int32), ("hidden", C.c_int32), ("ldx", C.c_int32), ("ldo", C.c_int32), ("ln", C.c_int32),
+        ("ln_eps", C.c_float),
+    ]
+
+
 SYMBOLS = {
     "tc_gemm_bf16": (C.c_int, [C.POINTER(TcGemmParams), C.c_void_p]),
     "tc_gemm_workspace": (C.c_int64, [C.POINTER(TcGemmParams)]),
@@ -105,6 +113,8 @@ SYMBOLS = {
     "tc_gemm_gn_rows": (C.c_int, [C.POINTER(TcGemmParams)]),
     "tc_groupnorm_part": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "tc_ff_geglu_fused_eligible": (C.c_int, [C.POINTER(TcFfParams)]),
+    "tc_ff_geglu_fused": (C.c_int, [C.POINTER(TcFfParams), C.c_void_p]),
     "tc_abi_version": (C.c_int, []),
     "tc_build_info": (C.c_char_p, []),
 }

@@ -46,14 +46,35 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below a bf16 ulp): branch-free and an
 // order of magnitude less code than libdevice's erff, which matters in the unrolled GEMM epilogue.
+// The reciprocal is the hardware's v_rcp_f32 (1 ulp): the correctly rounded one is an eleven-instruction
+// division sequence, and a GEGLU epilogue at K = 320 is bound by exactly this arithmetic, not by its MFMAs.
 __device__ __forceinline__ float erf_as(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float r = 1.0f - poly * __expf(-ax * ax);
   return copysignf(r, x);
 }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
+// GELU (erf form, torch.nn.functional.gelu's default) on the same approximation, arranged for the fewest VALU
+// instructions (11 full-rate + rcp + exp): with z = x / sqrt 2, t = 1 / (1 + p |z|) and u = P(t) exp(-z^2) / 2 (>= 0),
+//     x >= 0:  x (1 + erf z) / 2 = x - |x| u          x < 0:  x (1 - erf |z|) / 2 = -|x| u
+// i.e. gelu(x) = max(x, 0) - |x| u.
+__device__ __forceinline__ float gelu_erf_f(float x) {
+#if defined(TC_GELU_VARIANT) && TC_GELU_VARIANT == 0          /* experiment arms only (scripts/gelu_ab.sh) */
+  const float z = x * 0.70710678118654752440f, az = fabsf(z);
+  const float t0 = __frcp_rn(1.0f + 0.3275911f * az);
+  const float p0 = t0 * (0.254829592f + t0 * (-0.284496736f + t0 * (1.421413741f + t0 * (-1.453152027f + t0 * 1.061405429f))));
+  return 0.5f * x * (1.0f + copysignf(1.0f - p0 * __expf(-az * az), z));
+#elif defined(TC_GELU_VARIANT) && TC_GELU_VARIANT == 2
+  return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
+#endif
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(ax, 0.3275911f * 0.70710678118654752440f, 1.0f));
+  const float poly = t * (0.5f * 0.254829592f + t * (0.5f * -0.284496736f + t * (0.5f * 1.421413741f +
+                     t * (0.5f * -1.453152027f + t * (0.5f * 1.061405429f)))));
+  const float e = __builtin_amdgcn_exp2f((x * (-0.5f * 1.44269504088896340736f)) * x);
+  return __builtin_fmaf(-ax, poly * e, fmaxf(x, 0.0f));
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

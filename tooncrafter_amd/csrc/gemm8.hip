@@ -489,7 +489,11 @@ int tc_gemm8_try(const TcGemmParams& p, int batch, hipStream_t s, bool dry) {
     // kernel does NOT beat: level-1 3x3 640 -> 640 0.85x, 1920 -> 640 0.80x)
     const bool one_round = tiles >= 224 && tiles <= 256 && p.gather == TC_GATHER_LINEAR;
     const bool many = tiles >= 1024 && p.n % G8_BN == 0 && p.n >= 512 && p.k >= 4096;   // (256 -> 256 convolutions: 0.89-0.92x)
-    if (geglu || p.k < 2048 || n_eff < 0.8 || !(one_round || many)) return 0;
+    // GEGLU projections of levels 0 and 1 (81920 x 2560 x 320, 20480 x 5120 x 640: 3200 / 1600 tiles): once the GELU of
+    // the epilogue lost its division sequence (common.h gelu_erf_f) the kernel is ahead there too -- 1.09-1.13x and
+    // 1.06-1.09x (profiles/r04_gelu_ab.txt); level 2 (5120 x 10240 x 1280) stays behind (0.95x)
+    const bool gated = geglu && p.gather == TC_GATHER_LINEAR && tiles >= 1536 && p.k <= 640 && p.n % G8_BN == 0;
+    if (!gated && (geglu || p.k < 2048 || n_eff < 0.8 || !(one_round || many))) return 0;
   }
   const int64_t total = (int64_t)tiles_n * tiles_m;
   if (total > 0x7fffffffLL) return 0;

@@ -108,6 +108,12 @@ class FeedForward(PackedModule):
         """`ln` = (folded packed weight, folded bias, eps): `x_norm` is then the RAW rows and the LayerNorm runs as the
         prologue of the first GEMM (BasicTransformerBlock._pre)."""
         pk = self.pk
+        if ln is not None and x_norm is residual:
+            # level 0 (C = 320, hidden 1280): LayerNorm, both products, GEGLU and the residual as ONE launch -- the
+            # [rows, 1280] hidden tensor (210 MB per block at the BASELINE shape) never reaches HBM (csrc/ff_fused.hip)
+            probe = getattr(ops.backend(), "ff_fused_eligible", None)
+            if probe is not None and probe(x_norm.shape[0], x_norm.shape[1], pk["w2"].shape[1], ldx=x_norm.stride(0)):
+                return ops.ff_geglu_fused(x_norm, ln[0], ln[1], pk["w2"], pk["b2"], ln_eps=ln[2])
         if ln is not None:
             g = ops.gemm(x_norm, ln[0], ln[1], act=ACT_GEGLU, a_norm_eps=ln[2])
         else:
@@ -267,6 +273,10 @@ class BasicTransformerBlock(PackedModule):
         (K = 320 at level 0: ops.gemm_ln_eligible, the library's own rule) -- (x, folded consumer weights): the
         LayerNorm launch and its HBM round trip (reference attention.py:242-246 runs it as its own kernel) disappear."""
         gated = kind == "ff"
+        if gated:   # the one-launch feed-forward (csrc/ff_fused.hip) normalises its rows itself: raw rows + folded weights
+            fused = getattr(ops.backend(), "ff_fused_eligible", None)
+            if fused is not None and fused(x.shape[0], x.shape[1], self.ff.pk["w2"].shape[1], ldx=x.stride(0)):
+                return x, self._folded(i, kind)
         probe = getattr(ops.backend(), "gemm_ln_eligible", None)
         if probe is not None and probe(x.shape[0], consumer.shape[0], consumer.shape[1], geglu=gated, lda=x.stride(0)):
             return x, self._folded(i, kind)

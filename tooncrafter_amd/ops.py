@@ -23,7 +23,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_SILU, GATHER_CONV3x3, GATHER_CONVT3,
-                   GATHER_LINEAR, TcAttnParams, TcDdimParams, TcGemmMxParams, TcGemmParams)
+                   GATHER_LINEAR, TcAttnParams, TcDdimParams, TcFfParams, TcGemmMxParams, TcGemmParams)
 
 BF16 = torch.bfloat16
 
@@ -245,6 +245,41 @@ class HipOps:
         if not self.lib.tc_gemm_ws_eligible(C.byref(p)):
             return False
         return not (self.fp8 is not None and self._fp8_eligible(p, False, p.ldc, 1))
+
+    # ------------------------------------------------------------------ fused level-0 feed-forward (ABI 9)
+    def _ff_params(self, m, c, hidden, ldx, ldo, ln_eps):
+        p = TcFfParams()
+        p.m, p.c, p.hidden, p.ldx, p.ldo = int(m), int(c), int(hidden), int(ldx), int(ldo)
+        p.ln, p.ln_eps = (0, 0.0) if ln_eps is None else (1, float(ln_eps))
+        return p
+
+    def ff_fused_eligible(self, m, c, hidden, *, ldx=None) -> bool:
+        """Would `ff_geglu_fused(x[m, c], w1[2 hidden, c], ...)` be accepted?  The library's own rule
+        (tc_ff_geglu_fused_eligible: c = 320, hidden = 1280, TC_FF_FUSED != 0); never on the MXFP8 route, whose GEGLU
+        projection is a different kernel with its own numerics."""
+        if self.fp8 is not None:
+            return False
+        p = self._ff_params(m, c, hidden, c if ldx is None else ldx, c, 1e-5)
+        return bool(self.lib.tc_ff_geglu_fused_eligible(C.byref(p)))
+
+    def ff_geglu_fused(self, x, w1, b1, w2, b2, *, ln_eps=None):
+        """out = x + w2 . GEGLU(w1 . LN(x) + b1) + b2 as ONE launch (reference attention.py:415-442 behind norm3): the hidden
+        tensor never reaches HBM.  w1 / b1: the GEGLU projection exactly as `gemm(..., act=ACT_GEGLU)` takes it (with the
+        LayerNorm's affine half folded in when ln_eps is given); ln_eps=None: x is taken as already normalised."""
+        m, c = x.shape
+        hidden = w2.shape[1]
+        _dev(x, BF16, "ff_geglu_fused x", contiguous=False)
+        for t, dt, what in ((w1, BF16, "w1"), (w2, BF16, "w2"), (b1, torch.float32, "b1"), (b2, torch.float32, "b2")):
+            _dev(t, dt, "ff_geglu_fused " + what)
+        if x.stride(1) != 1 or tuple(w1.shape) != (2 * hidden, c) or tuple(w2.shape) != (c, hidden) or b1.numel() != 2 * hidden \
+                or b2.numel() != c:
+            raise ValueError("ff_geglu_fused: x [m, c] rows, w1 [2 hidden, c], b1 [2 hidden], w2 [c, hidden], b2 [c]")
+        out = torch.empty((m, c), dtype=BF16, device=x.device)
+        p = self._ff_params(m, c, hidden, x.stride(0), c, ln_eps)
+        p.x, p.w1, p.b1, p.w2, p.b2, p.out = (x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                              out.data_ptr())
+        _lib.check(self.lib.tc_ff_geglu_fused(C.byref(p), _stream()), "tc_ff_geglu_fused")
+        return out
 
     # ------------------------------------------------------------------ MXFP8 GEMM path (configs[4])
     def quant_mxfp8(self, x, k=None):
