@@ -22,8 +22,11 @@ DEV = "cuda"
 
 @pytest.fixture(scope="module")
 def hip():
+    """The operator set with producer statistics ON (TC_GN_PART=1; the product default is off: profiles/r04_gn_part_ab.txt)."""
     from tooncrafter_amd.ops import HipOps
-    return HipOps()
+    h = HipOps()
+    h.gn_part = True
+    return h
 
 
 @pytest.fixture(scope="module")
