@@ -45,28 +45,32 @@ def main():
             gg = hip.gemm(h, w1, b1, act=ACT_GEGLU)
             return hip.gemm(gg, w2, b2, residual=x)
 
-        t_ln = timeit(lambda: hip.layernorm(x, ones, zeros, 1e-5))
-        h = hip.layernorm(x, ones, zeros, 1e-5)
-        t_g = timeit(lambda: hip.gemm(h, w1, b1, act=ACT_GEGLU))
-        gg = hip.gemm(h, w1, b1, act=ACT_GEGLU)
-        t_2 = timeit(lambda: hip.gemm(gg, w2, b2, residual=x))
-        t_chain = timeit(chain)
-        print(f"rows {m}: LayerNorm {t_ln:.1f} us | GEGLU projection {t_g:.1f} us | ff2 + residual {t_2:.1f} us | chain {t_chain:.1f} us")
-        for grid in [int(v) for v in os.environ.get("FF_GRIDS", "0").split(",")]:
-            if grid:
-                os.environ["TC_FF_GRID"] = str(grid)
-            else:
-                os.environ.pop("TC_FF_GRID", None)
-            t_f = timeit(lambda: hip.ff_geglu_fused(x, w1, b1, w2, b2, ln_eps=1e-5))
-            for var, vals in (("TC_FF_LOOKAHEAD", os.environ.get("FF_LAS", "")), ("TC_FF_ABLATE", os.environ.get("FF_ABLS", ""))):
-                for v in [v for v in vals.split(",") if v]:
-                    os.environ[var] = v
-                    t_v = timeit(lambda: hip.ff_geglu_fused(x, w1, b1, w2, b2, ln_eps=1e-5))
-                    print(f"rows {m}:   {var}={v}: {t_v:.1f} us")
-                os.environ.pop(var, None)
-            d = (hip.ff_geglu_fused(x, w1, b1, w2, b2, ln_eps=1e-5).float() - chain().float()).abs().max()
-            print(f"rows {m}: fused (grid {grid or 'CUs'}) {t_f:.1f} us = {flops / t_f * 1e-6:.1f} TFLOP/s, "
-                  f"{t_chain / t_f:.2f}x the chain; max |fused - chain| {float(d):.3e}")
+        # arms, timed interleaved over several rounds (the clocks drift over the first seconds of load: an arm measured first
+        # reads ~8 % slower than the same arm measured last) -- medians
+        arms = [("chain: LayerNorm + GEGLU projection + ff2", {}, chain)]
+        fused = lambda: hip.ff_geglu_fused(x, w1, b1, w2, b2, ln_eps=1e-5)
+        arms.append(("fused (first after the chain: clocks in transit)", {}, fused))
+        arms.append(("fused", {}, fused))
+        for var, key in (("TC_FF_GRID", "FF_GRIDS"), ("TC_FF_LOOKAHEAD", "FF_LAS"), ("TC_FF_GILP", "FF_GILPS"), ("TC_FF_ABLATE", "FF_ABLS")):
+            for v in [v for v in os.environ.get(key, "").split(",") if v]:
+                arms.append((f"fused {var}={v}", {var: v}, fused))
+        arms.append(("fused (again)", {}, fused))
+        arms.append(("chain (again, first after fused)", {}, chain))
+        arms.append(("chain (again)", {}, chain))
+        times = [[] for _ in arms]
+        for rd in range(int(os.environ.get("FF_ROUNDS", "5")) + 1):
+            for i, (_, env, fn) in enumerate(arms):
+                os.environ.update(env)
+                t = timeit(fn, n=20, warm=3)
+                for k in env:
+                    os.environ.pop(k)
+                if rd:
+                    times[i].append(t)
+        med = [sorted(t)[len(t) // 2] for t in times]
+        d = (fused().float() - chain().float()).abs().max()
+        for (name, _, _), t in zip(arms, med):
+            print(f"rows {m}: {name:46s} {t:7.1f} us  {flops / t * 1e-6:6.1f} TFLOP/s  x{med[0] / t:.3f} vs chain")
+        print(f"rows {m}: max |fused - chain| {float(d):.3e}")
 
 
 if __name__ == "__main__":

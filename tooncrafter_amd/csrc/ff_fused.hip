@@ -63,7 +63,7 @@ __device__ __forceinline__ void ff_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(
 
 // LA: W1 K-tiles requested ahead (2 or 3 of the ring's 4 stages).  ABL: timing ablations (TC_FF_ABLATE; wrong results) --
 // 1 no GELU arithmetic, 2 no weight requests, 4 no ff1 MFMAs, 8 no ff2 MFMAs.
-template <int LA, int ABL>
+template <int LA, int ABL, int GI>
 __global__ __launch_bounds__(FF_THREADS, 2) void ff_fused_kernel(const FfArgs p) {
   __shared__ __attribute__((aligned(1024))) char smem[FF_LDS];
 
@@ -281,12 +281,16 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ff_fused_kernel(const FfArgs p)
         const int a2 = (hcol >> 3) ^ (2 * fhalf);
         char* const hbase[4] = {hrow + (a2 << 4), hrow + ((a2 ^ 1) << 4), hrow + ((a2 ^ 4) << 4), hrow + ((a2 ^ 5) << 4)};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int cr = (r & 3) + 8 * (r >> 2);
-          const int kr = (cr >> 1) & 7;                               // 0, 1, 4 or 5
-          const float h = (ABL & 1) ? (acc_v[r] + bv) * (acc_g[r] + bg) : (acc_v[r] + bv) * gelu_erf_f(acc_g[r] + bg);
-          *reinterpret_cast<bf16_t*>(hbase[(kr & 1) + (kr >> 2) * 2] + cr * 128) = (bf16_t)h;
-          if (r & 1) __builtin_amdgcn_sched_barrier(0);              // two values at a time: bounded temporaries, some overlap
+        for (int r = 0; r < 16; r += 2) {                             // register pairs: packed fp32 arithmetic
+          const int cr = (r & 3) + 8 * (r >> 2);                      // row of r; r + 1 is the next row (r is even)
+          const int kr = (cr >> 1) & 7;                               // 0, 1, 4 or 5 -- the same for both
+          const tc_f32x2 v = {acc_v[r] + bv, acc_v[r + 1] + bv};
+          const tc_f32x2 g = {acc_g[r] + bg, acc_g[r + 1] + bg};
+          const tc_f32x2 h = (ABL & 1) ? v * g : v * gelu_erf_f2(g);
+          char* const dst = hbase[(kr & 1) + (kr >> 2) * 2] + cr * 128;
+          *reinterpret_cast<bf16_t*>(dst) = (bf16_t)h[0];
+          *reinterpret_cast<bf16_t*>(dst + 128) = (bf16_t)h[1];
+          if ((r + 2) % GI == 0) __builtin_amdgcn_sched_barrier(0);   // GI values in flight: the chain of a GELU is ~20 dependent instructions
         }
         ++cw2;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the hidden values are in LDS, the W2 slice has landed
@@ -404,17 +408,19 @@ extern "C" int tc_ff_geglu_fused(const TcFfParams* p, void* stream) {
   const int rounds = (a.tiles + gmax - 1) / gmax;
   const int grid = (a.tiles + rounds - 1) / rounds;
   const int abl = [&] { const char* e = getenv("TC_FF_ABLATE"); return e ? atoi(e) : 0; }();
+  const int gi = [&] { const char* e = getenv("TC_FF_GILP"); return e ? atoi(e) : 8; }();
   const int la = [&] { const char* e = getenv("TC_FF_LOOKAHEAD"); return e ? atoi(e) : 3; }();
   const dim3 g((unsigned)grid), b(FF_THREADS);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define FF_LAUNCH(LA_, ABL_) hipLaunchKernelGGL((ff_fused_kernel<LA_, ABL_>), g, b, 0, st, a)
+#define FF_LAUNCH(LA_, ABL_) hipLaunchKernelGGL((ff_fused_kernel<LA_, ABL_, 2>), g, b, 0, st, a)
   if (abl == 1) FF_LAUNCH(3, 1);
   else if (abl == 2) FF_LAUNCH(3, 2);
   else if (abl == 3) FF_LAUNCH(3, 3);
   else if (abl == 12) FF_LAUNCH(3, 12);
   else if (abl == 15) FF_LAUNCH(3, 15);
+  else if (gi == 2) FF_LAUNCH(3, 0);
   else if (la == 2) FF_LAUNCH(2, 0);
-  else FF_LAUNCH(3, 0);
+  else hipLaunchKernelGGL((ff_fused_kernel<3, 0, 8>), g, b, 0, st, a);       // the product kernel
 #undef FF_LAUNCH
   TC_LAUNCH_CHECK();
   return TC_OK;

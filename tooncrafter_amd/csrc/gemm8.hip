@@ -398,8 +398,11 @@ __global__ __launch_bounds__(G8_THREADS, 2) void gemm8_kernel(const TcGemmParams
         float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         const float gt[8] = {glo[0], glo[1], glo[2], glo[3], ghi[0], ghi[1], ghi[2], ghi[3]};
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-          x[e] = (x[e] + bv[e]) * gelu_erf_f(gt[e] + bg[e]);
+        for (int e = 0; e < 8; e += 2) {        // pairs: packed fp32 arithmetic (common.h gelu_erf_f2)
+          const tc_f32x2 v = {x[e] + bv[e], x[e + 1] + bv[e + 1]};
+          const tc_f32x2 h = v * gelu_erf_f2(tc_f32x2{gt[e] + bg[e], gt[e + 1] + bg[e + 1]});
+          x[e] = h[0]; x[e + 1] = h[1];
+        }
         if (m < p.m && col_ok)
           *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(c_base) + (int64_t)m * p.ldc + n0) = pack8(x);
       };

@@ -129,13 +129,21 @@ __device__ __forceinline__ void epilogue_fast(const TcGemmParams& p, const float
 #pragma unroll
       for (int e = 0; e < 4; ++e) { gt[e] = lo[e]; gt[4 + e] = hi[e]; }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
+      for (int e = 0; e < 8; e += 2) {          // pairs: packed fp32 arithmetic (common.h gelu_erf_f2)
 #if defined(TC_ABLATE) && (TC_ABLATE & 8)      // scripts/ablate_gemm.sh: the GEGLU epilogue without its erf
-        if (PLAIN) x[e] = (x[e] + bv[e]) * (gt[e] + bg[e]);
+        if (PLAIN) { x[e] = (x[e] + bv[e]) * (gt[e] + bg[e]); x[e + 1] = (x[e + 1] + bv[e + 1]) * (gt[e + 1] + bg[e + 1]); }
 #else
-        if (PLAIN) x[e] = (x[e] + bv[e]) * gelu_erf_f(gt[e] + bg[e]);
+        if (PLAIN) {
+          const tc_f32x2 v = {x[e] + bv[e], x[e + 1] + bv[e + 1]};
+          const tc_f32x2 h = v * gelu_erf_f2(tc_f32x2{gt[e] + bg[e], gt[e + 1] + bg[e + 1]});
+          x[e] = h[0]; x[e + 1] = h[1];
+        }
 #endif
-        else x[e] = (x[e] * p.alpha + bv[e]) * gelu_erf_f(gt[e] * p.alpha + bg[e]) * p.out_scale;
+        else {
+          const tc_f32x2 v = {x[e] * p.alpha + bv[e], x[e + 1] * p.alpha + bv[e + 1]};
+          const tc_f32x2 h = v * gelu_erf_f2(tc_f32x2{gt[e] * p.alpha + bg[e], gt[e + 1] * p.alpha + bg[e + 1]}) * p.out_scale;
+          x[e] = h[0]; x[e + 1] = h[1];
+        }
       }
     } else {
 #pragma unroll

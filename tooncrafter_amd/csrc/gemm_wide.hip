@@ -262,8 +262,11 @@ __global__ __launch_bounds__(WTHREADS, 2) void gemm_wide_kernel(const TcGemmPara
             for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; bg[e] = g0[e]; bg[4 + e] = g1[e]; }
           }
 #pragma unroll
-          for (int e = 0; e < 8; ++e)
-            x[e] = (x[e] * p.alpha + bv[e]) * gelu_erf_f(gt[e] * p.alpha + bg[e]) * p.out_scale;
+          for (int e = 0; e < 8; e += 2) {      // pairs: packed fp32 arithmetic (common.h gelu_erf_f2)
+            const tc_f32x2 v = {x[e] * p.alpha + bv[e], x[e + 1] * p.alpha + bv[e + 1]};
+            const tc_f32x2 h = v * gelu_erf_f2(tc_f32x2{gt[e] * p.alpha + bg[e], gt[e + 1] * p.alpha + bg[e + 1]}) * p.out_scale;
+            x[e] = h[0]; x[e + 1] = h[1];
+          }
           if (p.out_f32) {
             float* op = reinterpret_cast<float*>(c_base) + (int64_t)m * p.ldc + n0;
             *reinterpret_cast<f32x4*>(op) = f32x4{x[0], x[1], x[2], x[3]};
