@@ -71,6 +71,33 @@ def main():
         for (name, _, _), t in zip(arms, med):
             print(f"rows {m}: {name:46s} {t:7.1f} us  {flops / t * 1e-6:6.1f} TFLOP/s  x{med[0] / t:.3f} vs chain")
         print(f"rows {m}: max |fused - chain| {float(d):.3e}")
+        # ---- in context: what a level-0 block runs around its feed-forward (the attention's output projection + residual
+        # before it, the next block's qkv projection after it -- both HBM-bound), events around the feed-forward only
+        wo = pack_linear(torch.randn(C, C, generator=g) * 0.05).cuda()
+        wqkv = pack_linear(torch.randn(3 * C, C, generator=g) * 0.05).cuda()
+        att = (torch.randn(m, C, generator=g)).to(torch.bfloat16).cuda()
+
+        def in_context(ff, reps=20):
+            tot = 0.0
+            for it in range(reps + 3):
+                xx = hip.gemm(att, wo, None, residual=x)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                y = ff(xx)
+                e1.record()
+                hip.gemm(y, wqkv, None)
+                torch.cuda.synchronize()
+                if it >= 3:
+                    tot += e0.elapsed_time(e1)
+            return tot / reps * 1e3
+
+        def ff_chain(xx):
+            h = hip.layernorm(xx, ones, zeros, 1e-5)
+            return hip.gemm(hip.gemm(h, w1, b1, act=ACT_GEGLU), w2, b2, residual=xx)
+
+        for rd in range(3):
+            print(f"rows {m}: in context (out-proj -> FF -> qkv), round {rd}: chain {in_context(ff_chain):7.1f} us | "
+                  f"fused {in_context(lambda xx: hip.ff_geglu_fused(xx, w1, b1, w2, b2, ln_eps=1e-5)):7.1f} us")
 
 
 if __name__ == "__main__":
