@@ -250,7 +250,7 @@ def measure_roofline_hbm(model, inp):
             fwd()
         n, ms, by = probe.summary()
     gbs = by / (ms * 1e-3) / 1e9
-    name, tj = _pmc_file("r03_pmc_gn_traffic.json")
+    name, tj = _pmc_file("r04_pmc_gn_traffic.json", "r03_pmc_gn_traffic.json")
     traffic = round(tj["traffic_bytes_per_launch"]) if tj is not None else None
     return {"bound": "hbm", "kernel": "tc_groupnorm (GroupNorm32 + SiLU over channels-last rows)",
             "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
@@ -317,12 +317,13 @@ def measure_roofline(model, inp):
     # HBM-side bytes per launch come from a separate rocprofv3 --pmc run of the same forward (counters cannot
     # be read from inside this process); the committed summary of that run is quoted with its provenance
     traffic, traffic_src = None, None
-    name, tj = _pmc_file("r03_pmc_unet_traffic.json", "r02_pmc_unet_traffic.json", "r01_v6_pmc_unet_traffic.json")
+    name, tj = _pmc_file("r04_pmc_unet_traffic.json", "r03_pmc_unet_traffic.json", "r02_pmc_unet_traffic.json", "r01_v6_pmc_unet_traffic.json")
     if tj is not None:
         traffic = round(tj["traffic_bytes_per_launch"])
         traffic_src = (f"profiles/{name}: (2*FETCH_SIZE + WRITE_SIZE) per tc_gemm_bf16 launch of a B=2 UNet forward, bytes; "
-                       "L2-miss (fabric) traffic incl. Infinity-Cache hits; %.1f GB per B=2 forward vs 43.2 GB algorithmic; "
-                       "a committed counter run, not measured in this process" % (tj["traffic_bytes_per_forward"] / 1e9))
+                       "L2-miss (fabric) traffic incl. Infinity-Cache hits; %.1f GB per B=2 forward vs %.1f GB algorithmic; "
+                       "a committed counter run, not measured in this process"
+                       % (tj["traffic_bytes_per_forward"] / 1e9, tj.get("algorithmic_bytes_per_b2_forward", 43.2e9) / 1e9))
     return {"bound": "mfma", "kernel": "tc_gemm_bf16 family (gemm_kernel / gemm16 / gemm_wide / gemm_ws / gemm8: Linear and "
                                        "implicit-GEMM convolutions, all gather modes; tc_ff_geglu_fused counted as the two products "
                                        "it fuses), UNet + decoder launches of one clip",
