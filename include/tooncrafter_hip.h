@@ -163,6 +163,24 @@ typedef struct TcFfParams {
 int tc_ff_geglu_fused_eligible(const TcFfParams* p);
 int tc_ff_geglu_fused(const TcFfParams* p, void* stream);
 
+/* ABI 9 -- the temporal self-attention of a level-0 transformer block as ONE launch (lvdm/modules/attention.py:81-144 over
+ * the T = 16 frames of a pixel, called from TemporalTransformer attention.py:365-412 behind norm1 / norm2, attention.py:
+ * 225-246):  out = x + wo . Attn_frames(wqkv . LN(x) + bqkv) + bo.  The [rows, 960] qkv tensor and the [rows, 320]
+ * attention output never reach HBM.  c = 320, heads = 5 (of 64), t = 16, hw % 8 == 0 only (tc_temporal_attn_fused_eligible).
+ *   x     [b*t*hw, ldx] bf16, row = (batch * t + frame) * hw + pixel: LayerNorm input AND residual;
+ *   wqkv  [3*c, c] bf16: rows [0, c) = to_q, [c, 2c) = to_k, [2c, 3c) = to_v (head h at h*64), the fused projection
+ *         tc_gemm_bf16 takes in front of tc_attn_temporal; with ln != 0 the LayerNorm's gamma is folded in and bqkv
+ *         carries wqkv . beta (zeros otherwise: the reference's projections have no bias);
+ *   wo    [c, c] bf16, bo [c] fp32 (to_out);   out [b*t*hw, ldo] bf16;   scale = 64^-0.5;
+ *   ln    != 0: rows are normalised ((x - mean) * rsqrt(var + ln_eps), fp32 statistics) before the projection. */
+typedef struct TcTbParams {
+  const tc_bf16* x; const tc_bf16* wqkv; const float* bqkv; const tc_bf16* wo; const float* bo; tc_bf16* out;
+  int32_t b, t, hw, c, heads, ldx, ldo, ln;
+  float ln_eps, scale;
+} TcTbParams;
+int tc_temporal_attn_fused_eligible(const TcTbParams* p);
+int tc_temporal_attn_fused(const TcTbParams* p, void* stream);
+
 typedef struct TcAttnParams {
   const tc_bf16* q; const tc_bf16* k; const tc_bf16* v; tc_bf16* o;
   int32_t batch, heads, lq, lk;

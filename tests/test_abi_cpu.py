@@ -31,7 +31,7 @@ def test_struct_layout_matches_header():
         header = f.read()
     for cname, ctype in (("TcGemmParams", _lib.TcGemmParams), ("TcAttnParams", _lib.TcAttnParams),
                          ("TcDdimParams", _lib.TcDdimParams), ("TcGemmMxParams", _lib.TcGemmMxParams),
-                         ("TcFfParams", _lib.TcFfParams)):
+                         ("TcFfParams", _lib.TcFfParams), ("TcTbParams", _lib.TcTbParams)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), header, re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []

@@ -64,3 +64,25 @@ def test_fused_mirror_equals_the_chain_it_replaces():
     err = float((got - ref).norm() / ref.norm())
     print("fused mirror vs fp64 chain: rel-L2", err)
     assert err < 6e-3
+
+
+def test_temporal_attention_takes_the_fused_operator_when_offered():
+    """BasicTransformerBlock.forward_temporal on the emulation: both self-attentions over the frames go through
+    temporal_attn_fused (ABI 9, csrc/tb_fused.hip) when the backend offers it for the width, with the LayerNorm-folded qkv."""
+    from test_ln_fusion_cpu import _make_block
+    temporal = _make_block(None)
+    outs = {}
+    for c in (None, 320, 640):
+        emu = EmuOps(round_bf16=True, tb_fused_c=c)
+        prev = ops.set_backend(emu)
+        try:
+            b, t, h, w = 1, 16, 2, 4
+            x = torch.randn(b * t * h * w, 320, generator=torch.Generator().manual_seed(5)).to(torch.bfloat16)
+            with torch.no_grad():
+                outs[c] = temporal.forward_temporal(x, Act(x, b, t, h, w)).float()
+        finally:
+            ops.set_backend(prev)
+        assert emu.tb_fused_calls == (2 if c == 320 else 0), (c, emu.tb_fused_calls)
+    rel = float((outs[320] - outs[None]).norm() / outs[None].norm())
+    print("fused temporal attention on/off (emulation):", rel)
+    assert rel < 1e-2 and torch.equal(outs[640], outs[None])

@@ -77,6 +77,15 @@ class TcFfParams(C.Structure):
     ]
 
 
+class TcTbParams(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("wqkv", C.c_void_p), ("bqkv", C.c_void_p), ("wo", C.c_void_p), ("bo", C.c_void_p), ("out", C.c_void_p),
+        ("b", C.c_int32), ("t", C.c_int32), ("hw", C.c_int32), ("c", C.c_int32), ("heads", C.c_int32),
+        ("ldx", C.c_int32), ("ldo", C.c_int32), ("ln", C.c_int32),
+        ("ln_eps", C.c_float), ("scale", C.c_float),
+    ]
+
+
 SYMBOLS = {
     "tc_gemm_bf16": (C.c_int, [C.POINTER(TcGemmParams), C.c_void_p]),
     "tc_gemm_workspace": (C.c_int64, [C.POINTER(TcGemmParams)]),
@@ -115,6 +124,8 @@ SYMBOLS = {
                                     C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "tc_ff_geglu_fused_eligible": (C.c_int, [C.POINTER(TcFfParams)]),
     "tc_ff_geglu_fused": (C.c_int, [C.POINTER(TcFfParams), C.c_void_p]),
+    "tc_temporal_attn_fused_eligible": (C.c_int, [C.POINTER(TcTbParams)]),
+    "tc_temporal_attn_fused": (C.c_int, [C.POINTER(TcTbParams), C.c_void_p]),
     "tc_abi_version": (C.c_int, []),
     "tc_build_info": (C.c_char_p, []),
 }

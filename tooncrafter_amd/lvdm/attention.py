@@ -297,11 +297,21 @@ class BasicTransformerBlock(PackedModule):
         out = self.ff(h, x, ln=ln)
         return out if share is None else (out, act)
 
+    def _temporal_attn(self, x, i, attn, act: Act):
+        """x + attn(norm<i>(x)) over the frames of every pixel.  Level 0 (C = 320, 5 heads, 16 frames): LayerNorm, qkv
+        projection, the 16 x 16 attentions, output projection and the residual as ONE launch -- the [rows, 960] qkv tensor
+        and the attention output never reach HBM (csrc/tb_fused.hip); elsewhere the four launches."""
+        fused = getattr(ops.backend(), "temporal_attn_fused_eligible", None)
+        if fused is not None and fused(b=act.b, t=act.t, hw=act.hw, c=x.shape[1], heads=attn.heads, ldx=x.stride(0)):
+            w, bias, eps = self._folded(i, "qkv")
+            return ops.temporal_attn_fused(x, w, bias, attn.pk["wo"], attn.pk["bo"], b=act.b, t=act.t, hw=act.hw,
+                                           heads=attn.heads, ln_eps=eps, scale=attn.scale)
+        h, ln = self._pre(x, i, attn.pk["wqkv"], "qkv")
+        return attn.forward_temporal_self(h, x, act, ln=ln)
+
     def forward_temporal(self, x, act: Act):
-        h, ln = self._pre(x, 1, self.attn1.pk["wqkv"], "qkv")
-        x = self.attn1.forward_temporal_self(h, x, act, ln=ln)
-        h, ln = self._pre(x, 2, self.attn2.pk["wqkv"], "qkv")            # context=None -> self attention again
-        x = self.attn2.forward_temporal_self(h, x, act, ln=ln)
+        x = self._temporal_attn(x, 1, self.attn1, act)
+        x = self._temporal_attn(x, 2, self.attn2, act)                   # context=None -> self attention again
         h, ln = self._pre(x, 3, self.ff.pk["w1"], "ff")
         return self.ff(h, x, ln=ln)
 

@@ -23,7 +23,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_SILU, GATHER_CONV3x3, GATHER_CONVT3,
-                   GATHER_LINEAR, TcAttnParams, TcDdimParams, TcFfParams, TcGemmMxParams, TcGemmParams)
+                   GATHER_LINEAR, TcAttnParams, TcDdimParams, TcFfParams, TcGemmMxParams, TcGemmParams, TcTbParams)
 
 BF16 = torch.bfloat16
 
@@ -279,6 +279,41 @@ class HipOps:
         p.x, p.w1, p.b1, p.w2, p.b2, p.out = (x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
                                               out.data_ptr())
         _lib.check(self.lib.tc_ff_geglu_fused(C.byref(p), _stream()), "tc_ff_geglu_fused")
+        return out
+
+    # ------------------------------------------------------------------ fused level-0 temporal self-attention (ABI 9)
+    def _tb_params(self, b, t, hw, c, heads, ldx, ldo, ln_eps, scale):
+        p = TcTbParams()
+        p.b, p.t, p.hw, p.c, p.heads, p.ldx, p.ldo = int(b), int(t), int(hw), int(c), int(heads), int(ldx), int(ldo)
+        p.ln, p.ln_eps = (0, 0.0) if ln_eps is None else (1, float(ln_eps))
+        p.scale = float(64 ** -0.5 if scale is None else scale)
+        return p
+
+    def temporal_attn_fused_eligible(self, *, b, t, hw, c, heads, ldx=None) -> bool:
+        """Would `temporal_attn_fused` be accepted?  The library's own rule (tc_temporal_attn_fused_eligible: c = 320, 5 heads,
+        16 frames, hw % 8 == 0, TC_TB_FUSED != 0); never on the MXFP8 route."""
+        if self.fp8 is not None:
+            return False
+        p = self._tb_params(b, t, hw, c, heads, c if ldx is None else ldx, c, 1e-5, None)
+        return bool(self.lib.tc_temporal_attn_fused_eligible(C.byref(p)))
+
+    def temporal_attn_fused(self, x, wqkv, bqkv, wo, bo, *, b, t, hw, heads, ln_eps=None, scale=None):
+        """out = x + wo . Attn_frames(wqkv . LN(x) + bqkv) + bo as ONE launch (reference attention.py:81-144 over the frames of
+        a pixel, TemporalTransformer attention.py:365-412): the qkv tensor and the attention output never reach HBM.  wqkv:
+        the fused projection `gemm` takes in front of `attention_temporal` (LayerNorm's affine half folded in when ln_eps is
+        given, bqkv = its bias; zeros otherwise)."""
+        m, c = x.shape
+        _dev(x, BF16, "temporal_attn_fused x", contiguous=False)
+        for tns, dt, what in ((wqkv, BF16, "wqkv"), (wo, BF16, "wo"), (bqkv, torch.float32, "bqkv"), (bo, torch.float32, "bo")):
+            _dev(tns, dt, "temporal_attn_fused " + what)
+        if x.stride(1) != 1 or m != b * t * hw or tuple(wqkv.shape) != (3 * c, c) or tuple(wo.shape) != (c, c) \
+                or bqkv.numel() != 3 * c or bo.numel() != c or c != heads * 64:
+            raise ValueError("temporal_attn_fused: x [b*t*hw, c] rows, wqkv [3c, c], bqkv [3c], wo [c, c], bo [c], c = heads * 64")
+        out = torch.empty((m, c), dtype=BF16, device=x.device)
+        p = self._tb_params(b, t, hw, c, heads, x.stride(0), c, ln_eps, scale)
+        p.x, p.wqkv, p.bqkv, p.wo, p.bo, p.out = (x.data_ptr(), wqkv.data_ptr(), bqkv.data_ptr(), wo.data_ptr(), bo.data_ptr(),
+                                                  out.data_ptr())
+        _lib.check(self.lib.tc_temporal_attn_fused(C.byref(p), _stream()), "tc_temporal_attn_fused")
         return out
 
     # ------------------------------------------------------------------ MXFP8 GEMM path (configs[4])
