@@ -156,6 +156,7 @@ class GemmProbe:
         self.b = backend
         self.orig = backend.gemm
         self.orig_ff = getattr(backend, "ff_geglu_fused", None)
+        self.orig_tb = getattr(backend, "temporal_attn_fused", None)
         self.rec = []
 
     def __enter__(self):
@@ -167,6 +168,16 @@ class GemmProbe:
             out = self.orig_ff(x, w1, b1, w2, b2, **kw)
             e1.record()
             self.rec.append((e0, e1, 2.0 * x.shape[0] * (w1.shape[0] * w1.shape[1] + w2.shape[0] * w2.shape[1])))
+            return out
+
+        def tb(x, wqkv, bqkv, wo, bo, **kw):
+            # the one-launch temporal self-attention (tc_temporal_attn_fused): counted with the family at the FLOPs of the
+            # two projections it fuses (the 16 x 16 attentions in between were never part of the family)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = self.orig_tb(x, wqkv, bqkv, wo, bo, **kw)
+            e1.record()
+            self.rec.append((e0, e1, 2.0 * x.shape[0] * (wqkv.shape[0] * wqkv.shape[1] + wo.shape[0] * wo.shape[1])))
             return out
 
         def gemm(a, w, bias=None, **kw):
@@ -182,12 +193,16 @@ class GemmProbe:
         self.b.gemm = gemm
         if self.orig_ff is not None:
             self.b.ff_geglu_fused = ff
+        if self.orig_tb is not None:
+            self.b.temporal_attn_fused = tb
         return self
 
     def __exit__(self, *a):
         self.b.gemm = self.orig
         if self.orig_ff is not None:
             self.b.ff_geglu_fused = self.orig_ff
+        if self.orig_tb is not None:
+            self.b.temporal_attn_fused = self.orig_tb
 
     def summary(self):
         torch.cuda.synchronize()
@@ -325,8 +340,8 @@ def measure_roofline(model, inp):
                        "a committed counter run, not measured in this process"
                        % (tj["traffic_bytes_per_forward"] / 1e9, tj.get("algorithmic_bytes_per_b2_forward", 43.2e9) / 1e9))
     return {"bound": "mfma", "kernel": "tc_gemm_bf16 family (gemm_kernel / gemm16 / gemm_wide / gemm_ws / gemm8: Linear and "
-                                       "implicit-GEMM convolutions, all gather modes; tc_ff_geglu_fused counted as the two products "
-                                       "it fuses), UNet + decoder launches of one clip",
+                                       "implicit-GEMM convolutions, all gather modes; tc_ff_geglu_fused / tc_temporal_attn_fused counted as the "
+                                       "two products each fuses), UNet + decoder launches of one clip",
             "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "launches": n, "avg_launch_us": round(ms * 1e3 / max(n, 1), 2),

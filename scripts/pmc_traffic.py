@@ -20,7 +20,7 @@ def sums(db, counter):
     for k, cn, v in c.execute(f"select {kcol}, {ccol}, {vcol} from {view}"):
         if cn != counter:
             continue
-        fam = "gemm" if ("gemm" in k and "splitk" not in k) or "ff_fused" in k else "gn" if ("gn_" in k) else None
+        fam = "gemm" if ("gemm" in k and "splitk" not in k) or "ff_fused" in k or "tb_fused" in k else "gn" if ("gn_" in k) else None
         if fam is None:
             continue
         a = agg.setdefault(fam, {"sum": 0.0, "rows": 0, "kernels": {}})
