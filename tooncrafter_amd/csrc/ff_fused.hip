@@ -61,7 +61,8 @@ struct FfArgs {
 template <int N>
 __device__ __forceinline__ void ff_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// LA: W1 K-tiles requested ahead (2 or 3 of the ring's 4 stages).  ABL: timing ablations (TC_FF_ABLATE; wrong results) --
+// LA: W1 K-tiles requested ahead (2 or 3 of the ring's 4 stages; 4 = three ahead with the requests issued in the MFMA segment,
+// between the MFMAs, instead of in the read segment: 274-280 us against 265-268, profiles/r04_ff_fused_bench.txt -- kept as a switch).  ABL: timing ablations (TC_FF_ABLATE; wrong results) --
 // 1 no GELU arithmetic, 2 no weight requests, 4 no ff1 MFMAs, 8 no ff2 MFMAs.
 template <int LA, int ABL, int GI>
 __global__ __launch_bounds__(FF_THREADS, 2) void ff_fused_kernel(const FfArgs p) {
@@ -105,6 +106,13 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ff_fused_kernel(const FfArgs p)
     g8_dma16(w1_srd, dst, v1, so);
     g8_dma16(w1_srd, dst + 8192, v1, so + 64 * FF_C * 2);
   };
+  auto dma_w1_half = [&](int q, int half) {                           // one of the K-tile's two pieces (LA == 4)
+    if constexpr (ABL & 2) return;
+    const int qq = q % (FF_NCH * FF_KT);
+    const int c = qq / FF_KT, kt = qq - c * FF_KT;
+    const uint32_t so = (uint32_t)((c * 128 * FF_C + kt * TC_BK) * 2) + (uint32_t)half * (64 * FF_C * 2);
+    g8_dma16(w1_srd, dma_dst + FF_W1_OFF + (q & 3) * FF_W1_STAGE + half * 8192, v1, so);
+  };
   auto dma_w2 = [&](int c, int piece) {                               // rows 64 piece .. +64 of W2's slice for hidden chunk c
     if constexpr (ABL & 2) return;
     const int cc = c % FF_NCH;
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ff_fused_kernel(const FfArgs p)
   // prologue of the stream: W1(0), W1(1)
   dma_w1(0);
   dma_w1(1);
-  if constexpr (LA == 3) dma_w1(2);
+  if constexpr (LA >= 3) dma_w1(2);
   ff_wait_vmcnt<0>();
   g8_barrier();
 
@@ -211,20 +219,29 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ff_fused_kernel(const FfArgs p)
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) bw[j][kk] = *reinterpret_cast<const bf16x8*>(st + j * 4096 + coff(kk));
-        dma_w1(q + LA);
-        if (s == 1) { dma_w2(cw2, 0); dma_w2(cw2, 1); }
-        if (s >= 2) { dma_w2(cw2, s); }
+        if constexpr (LA != 4) {
+          dma_w1(q + LA);
+          if (s == 1) { dma_w2(cw2, 0); dma_w2(cw2, 1); }
+          if (s >= 2) { dma_w2(cw2, s); }
+        }
         // the K-tile the NEXT step reads has landed (this wave's pieces; the barrier makes it everybody's): the counts are
         // the requests issued after it -- see the table above the steps
         if constexpr (LA == 2) {
           if (s == 0) ff_wait_vmcnt<2>();
           else if (s == 2) ff_wait_vmcnt<5>();
           else ff_wait_vmcnt<4>();
-        } else {
+        } else if constexpr (LA == 3) {
           if (s == 0) ff_wait_vmcnt<2>();
           else if (s == 1) ff_wait_vmcnt<6>();
           else if (s == 3) ff_wait_vmcnt<8>();
           else ff_wait_vmcnt<7>();
+        } else {
+          // requests in the MFMA segments: M_s issues W1(q + 3) (two pieces), then piece s of this chunk's W2 slice.  The
+          // tile the next step reads was requested two MFMA segments ago, first there; behind it: that segment's W2 piece
+          // and the last segment's three requests (across the chunk seam everything was drained at the end of G)
+          if (s == 0) ff_wait_vmcnt<0>();
+          else if (s == 1) ff_wait_vmcnt<3>();
+          else ff_wait_vmcnt<4>();
         }
         g8_barrier();
         __builtin_amdgcn_s_setprio(1);
@@ -242,10 +259,26 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ff_fused_kernel(const FfArgs p)
           }
           if constexpr (s == 4) __builtin_amdgcn_sched_barrier(0);
         };
-        mm(ic<0>{});
-        mm(ic<1>{});
-        mm(ic<2>{});
-        mm(ic<3>{});
+        if constexpr (LA == 4) {
+          mm(ic<0>{});
+          __builtin_amdgcn_sched_barrier(0);
+          dma_w1_half(q + 3, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          mm(ic<1>{});
+          __builtin_amdgcn_sched_barrier(0);
+          dma_w1_half(q + 3, 1);
+          __builtin_amdgcn_sched_barrier(0);
+          mm(ic<2>{});
+          __builtin_amdgcn_sched_barrier(0);
+          dma_w2(cw2, s);
+          __builtin_amdgcn_sched_barrier(0);
+          mm(ic<3>{});
+        } else {
+          mm(ic<0>{});
+          mm(ic<1>{});
+          mm(ic<2>{});
+          mm(ic<3>{});
+        }
         __builtin_amdgcn_s_setprio(0);
         g8_barrier();
         ++q;
@@ -420,6 +453,7 @@ extern "C" int tc_ff_geglu_fused(const TcFfParams* p, void* stream) {
   else if (abl == 15) FF_LAUNCH(3, 15);
   else if (gi == 2) FF_LAUNCH(3, 0);
   else if (la == 2) FF_LAUNCH(2, 0);
+  else if (la == 4) hipLaunchKernelGGL((ff_fused_kernel<4, 0, 8>), g, b, 0, st, a);
   else hipLaunchKernelGGL((ff_fused_kernel<3, 0, 8>), g, b, 0, st, a);       // the product kernel
 #undef FF_LAUNCH
   TC_LAUNCH_CHECK();
