@@ -56,6 +56,7 @@ struct FfArgs {
   int m, ldx, ldo, ln;
   float eps;
   int tiles;
+  unsigned long long* trace;     // TC_FF_TRACE (ABL bit 16 build): s_memtime after every barrier of block 0's waves 0 and 4
 };
 
 template <int N>
@@ -138,6 +139,20 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ff_fused_kernel(const FfArgs p)
   f32x16 out_acc[5];
   f32x16 acc_v, acc_g;
 
+  // ABL bit 16: per-interval timing.  Block 0, waves 0 (group 0) and 4 (group 1), second tile, first three chunks: the
+  // shader clock after every barrier -> trace[wave >> 2][n]
+  int tr_n = 0;
+  bool tr_on = false;
+  auto bar = [&]() {
+    g8_barrier();
+    if constexpr (ABL & 16) {
+      if (tr_on && tr_n < 64) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (lane == 0) p.trace[(wave_u >> 2) * 64 + tr_n] = t;
+        ++tr_n;
+      }
+    }
+  };
   int q = 0;                                          // W1 K-tile stream position consumed next (cyclic)
   int cw2 = 0;                                        // hidden chunk whose W2 slice is requested next (cyclic): the one
                                                       // the CURRENT chunk's ff2 reads -- requested during its ff1 steps
@@ -208,6 +223,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ff_fused_kernel(const FfArgs p)
     // before the epilogue, so that the two groups' epilogues and row loads -- long, barrier-free -- run side by side)
     if (grp == 1) g8_barrier();
     for (int c = 0; c < FF_NCH; ++c) {
+      if constexpr (ABL & 16) tr_on = blockIdx.x == 0 && (wave_u & 3) == 0 && tile == (int)(blockIdx.x + gridDim.x) && c < 3;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc_v[r] = 0.f; acc_g[r] = 0.f; }
       // ---- ff1: five K-steps; step s reads W1 K-tile q (ring stage q & 3) and requests K-tile q + 2
@@ -243,7 +259,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ff_fused_kernel(const FfArgs p)
           else if (s == 1) ff_wait_vmcnt<3>();
           else ff_wait_vmcnt<4>();
         }
-        g8_barrier();
+        bar();
         __builtin_amdgcn_s_setprio(1);
         auto mm = [&](auto KK_) {
           constexpr int kk = decltype(KK_)::value, ks = 4 * s + kk;
@@ -280,7 +296,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ff_fused_kernel(const FfArgs p)
           mm(ic<3>{});
         }
         __builtin_amdgcn_s_setprio(0);
-        g8_barrier();
+        bar();
         ++q;
       };
       // Requests in program order, per chunk (W1 = two pieces per thread, a W2 piece = one; the W2 slice requested is THIS
@@ -327,11 +343,11 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ff_fused_kernel(const FfArgs p)
         }
         ++cw2;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the hidden values are in LDS, the W2 slice has landed
-        g8_barrier();
+        bar();
       }
       // ---- X: the other group's G -- its threads' pieces of the W2 slice are only known to have landed after ITS drain --
       // an empty interval for this group (the hidden rows a group reads are written by that group alone)
-      g8_barrier();
+      bar();
       // ---- ff2: [32 x 64] hidden (A, from LDS) x W2 slice [160 x 64] (B, from LDS) -> out_acc, 20 MFMAs
       {
         const char* hb = smem + FF_H_OFF + (c & 1) * FF_H_BYTES + h_row();
@@ -343,7 +359,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ff_fused_kernel(const FfArgs p)
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) b2[j][kk] = *reinterpret_cast<const bf16x8*>(wb + j * 4096 + coff(kk));
-        g8_barrier();
+        bar();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
@@ -359,7 +375,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ff_fused_kernel(const FfArgs p)
           __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_setprio(0);
-        g8_barrier();
+        bar();
       }
     }
 
@@ -434,6 +450,7 @@ extern "C" int tc_ff_geglu_fused(const TcFfParams* p, void* stream) {
   a.w2 = reinterpret_cast<const bf16_t*>(p->w2); a.b2 = p->b2; a.out = reinterpret_cast<bf16_t*>(p->out);
   a.m = p->m; a.ldx = p->ldx; a.ldo = p->ldo; a.ln = p->ln ? 1 : 0; a.eps = p->ln_eps;
   a.tiles = (p->m + FF_BM - 1) / FF_BM;
+  a.trace = [&]() -> unsigned long long* { const char* e = getenv("TC_FF_TRACE"); return e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0)) : nullptr; }();
   static const int cus = [] { int d = 0, n = 256; if (hipGetDevice(&d) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
   const int gmax = [&] { const char* e = getenv("TC_FF_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : cus; }();
   // every block the same number of tiles: 640 tiles on 256 CUs are three rounds either way, and 214 blocks of three
@@ -451,6 +468,7 @@ extern "C" int tc_ff_geglu_fused(const TcFfParams* p, void* stream) {
   else if (abl == 3) FF_LAUNCH(3, 3);
   else if (abl == 12) FF_LAUNCH(3, 12);
   else if (abl == 15) FF_LAUNCH(3, 15);
+  else if (abl == 16 && a.trace) FF_LAUNCH(3, 16);
   else if (gi == 2) FF_LAUNCH(3, 0);
   else if (la == 2) FF_LAUNCH(2, 0);
   else if (la == 4) hipLaunchKernelGGL((ff_fused_kernel<4, 0, 8>), g, b, 0, st, a);
