@@ -57,7 +57,8 @@ struct TbArgs {
   int hw, ldx, ldo, ln;
   float eps, scale_log2e;
   int tiles, tiles_per_b;
-  int abl;          // timing ablations (TC_TB_ABLATE; wrong results): 1 no head loop (row loads, LayerNorm, epilogue only), 2 no row loads, 4 no epilogue
+  int abl;          // timing ablations (TC_TB_ABLATE; wrong results): 1 no head loop (row loads, LayerNorm, epilogue only), 2 no row loads, 4 no epilogue, 8 interval trace (TC_TB_TRACE)
+  unsigned long long* trace;   // TC_TB_TRACE (with TC_TB_ABLATE bit 8): s_memtime after every barrier of block 0's waves 0 and 4
   int stagger;      // TC_TB_STAGGER: block i starts (i & 3) * stagger * ~3.4 us late (de-phases the blocks' memory phases)
 };
 
@@ -148,6 +149,19 @@ __global__ __launch_bounds__(TB_THREADS, 2) void tb_fused_kernel(const TbArgs p)
   f32x16 out_acc[5];
   f32x16 acc_v, acc_g;                              // the stage's 32 x 64 block of the wave: columns 0..31 | 32..63
 
+  // abl bit 8: per-interval timing.  Block 0, waves 0 (group 0) and 4 (group 1), second tile, first two heads: the shader clock
+  // after every barrier -> trace[wave >> 2][n] (a store per barrier: the timed build is not the product kernel's schedule to the
+  // cycle, its waits are the same)
+  int tr_n = 0;
+  bool tr_on = false;
+  auto bar = [&]() {
+    g8_barrier();
+    if ((p.abl & 8) && tr_on && tr_n < 64) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      if (lane == 0) p.trace[(wave_u >> 2) * 64 + tr_n] = t;
+      ++tr_n;
+    }
+  };
   for (int i = (blockIdx.x & 3) * p.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(127);
   int q = 0;                                        // K-tile stream position consumed next
   dma_w(0);
@@ -212,6 +226,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void tb_fused_kernel(const TbArgs p)
 
     if (grp == 1) g8_barrier();                     // the stagger, per tile (ff_fused.hip)
     for (int h = (p.abl & 1) ? TB_HEADS : 0; h < TB_HEADS; ++h) {
+      tr_on = (p.abl & 8) && blockIdx.x == 0 && (wave_u & 3) == 0 && tile == (int)(blockIdx.x + gridDim.x) && h < 2;
       // ---- one K-step of a stage: fragments of W K-tile q (ring stage q % 3), K-tile q + 2 and this step's share of Wo's
       // slice requested, 8 MFMAs.  Requests per head in program order (pieces per thread):
       //   A0: W 2 | A1: W 2 | A2: W 2 | A3: W 1 | A4: W 1 | B0: W 1 | B1: W 1, p0, p1 | B2: W 1, p2 | B3: W 2, p3 | B4: W 2, p4
@@ -236,7 +251,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void tb_fused_kernel(const TbArgs p)
         constexpr int pos = stage * 5 + s;
         constexpr int keep = pos <= 2 ? 2 : (pos <= 5 ? 1 : (pos == 6 ? 3 : 4));
         tb_wait_vmcnt<keep>();
-        g8_barrier();
+        bar();
         __builtin_amdgcn_s_setprio(1);
         if (act) {
           auto mm = [&](auto KK_) {
@@ -257,7 +272,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void tb_fused_kernel(const TbArgs p)
           mm(ic<3>{});
         }
         __builtin_amdgcn_s_setprio(0);
-        g8_barrier();
+        bar();
         ++q;
       };
       // ---- write-out of a stage's block: + bias, bf16.  q / k: row-major [128][64], 16-byte chunks XOR-swizzled by
@@ -312,7 +327,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void tb_fused_kernel(const TbArgs p)
       step(ic<0>{}, ic<4>{});
       write_qk();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      g8_barrier();
+      bar();
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc_v[r] = 0.f; acc_g[r] = 0.f; }
       step(ic<1>{}, ic<0>{});
@@ -322,7 +337,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void tb_fused_kernel(const TbArgs p)
       step(ic<1>{}, ic<4>{});
       write_vt();
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // q, k, v of the head are in LDS; this thread's Wo pieces landed
-      g8_barrier();
+      bar();
 
       // ---- attention of ONE pixel per wave (rows pr .. pr + 16 of the tile = its 16 frames), 16x16x32 MFMAs.
       // (The other group's Wo pieces are only known to have landed after ITS drain, one interval behind this one: this
@@ -391,7 +406,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void tb_fused_kernel(const TbArgs p)
             *reinterpret_cast<bf16_t*>(dst) = (bf16_t)od[db][r];
           }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        g8_barrier();
+        bar();
       }
 
       // ---- output projection: [32 x 64] head output (A, from LDS) x Wo slice [160 x 64] (B, from LDS) -> out_acc, 20 MFMAs
@@ -405,7 +420,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void tb_fused_kernel(const TbArgs p)
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) b2[j][kk] = *reinterpret_cast<const bf16x8*>(wb + j * 4096 + coff(kk));
-        g8_barrier();
+        bar();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
@@ -420,7 +435,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void tb_fused_kernel(const TbArgs p)
           __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_setprio(0);
-        g8_barrier();
+        bar();
       }
     }
 
@@ -498,6 +513,8 @@ extern "C" int tc_temporal_attn_fused(const TcTbParams* p, void* stream) {
   a.tiles = p->b * a.tiles_per_b;
   static const int cus = [] { int d = 0, n = 256; if (hipGetDevice(&d) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
   a.abl = [&] { const char* e = getenv("TC_TB_ABLATE"); return e ? atoi(e) : 0; }();
+  a.trace = [&]() -> unsigned long long* { const char* e = getenv("TC_TB_TRACE"); return e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0)) : nullptr; }();
+  if (!a.trace) a.abl &= ~8;
   a.stagger = [&] { const char* e = getenv("TC_TB_STAGGER"); return e ? atoi(e) : 0; }();
   const int gmax = [&] { const char* e = getenv("TC_TB_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : cus; }();
   const int rounds = (a.tiles + gmax - 1) / gmax;
