@@ -91,6 +91,7 @@ __device__ __forceinline__ float tb_sum_rows(float x) {
 template <int N>
 __device__ __forceinline__ void tb_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+template <bool TRACE>
 __global__ __launch_bounds__(TB_THREADS, 2) void tb_fused_kernel(const TbArgs p) {
   __shared__ __attribute__((aligned(1024))) char smem[TB_LDS];
 
@@ -149,17 +150,19 @@ __global__ __launch_bounds__(TB_THREADS, 2) void tb_fused_kernel(const TbArgs p)
   f32x16 out_acc[5];
   f32x16 acc_v, acc_g;                              // the stage's 32 x 64 block of the wave: columns 0..31 | 32..63
 
-  // abl bit 8: per-interval timing.  Block 0, waves 0 (group 0) and 4 (group 1), second tile, first two heads: the shader clock
+  // TRACE build (abl bit 8): per-interval timing.  Block 0, waves 0 (group 0) and 4 (group 1), second tile, first two heads: the shader clock
   // after every barrier -> trace[wave >> 2][n] (a store per barrier: the timed build is not the product kernel's schedule to the
   // cycle, its waits are the same)
   int tr_n = 0;
   bool tr_on = false;
   auto bar = [&]() {
     g8_barrier();
-    if ((p.abl & 8) && tr_on && tr_n < 64) {
-      const unsigned long long t = __builtin_amdgcn_s_memtime();
-      if (lane == 0) p.trace[(wave_u >> 2) * 64 + tr_n] = t;
-      ++tr_n;
+    if constexpr (TRACE) {
+      if (tr_on && tr_n < 64) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (lane == 0) p.trace[(wave_u >> 2) * 64 + tr_n] = t;
+        ++tr_n;
+      }
     }
   };
   for (int i = (blockIdx.x & 3) * p.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(127);
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void tb_fused_kernel(const TbArgs p)
 
     if (grp == 1) g8_barrier();                     // the stagger, per tile (ff_fused.hip)
     for (int h = (p.abl & 1) ? TB_HEADS : 0; h < TB_HEADS; ++h) {
-      tr_on = (p.abl & 8) && blockIdx.x == 0 && (wave_u & 3) == 0 && tile == (int)(blockIdx.x + gridDim.x) && h < 2;
+      if constexpr (TRACE) tr_on = blockIdx.x == 0 && (wave_u & 3) == 0 && tile == (int)(blockIdx.x + gridDim.x) && h < 2;
       // ---- one K-step of a stage: fragments of W K-tile q (ring stage q % 3), K-tile q + 2 and this step's share of Wo's
       // slice requested, 8 MFMAs.  Requests per head in program order (pieces per thread):
       //   A0: W 2 | A1: W 2 | A2: W 2 | A3: W 1 | A4: W 1 | B0: W 1 | B1: W 1, p0, p1 | B2: W 1, p2 | B3: W 2, p3 | B4: W 2, p4
@@ -519,7 +522,8 @@ extern "C" int tc_temporal_attn_fused(const TcTbParams* p, void* stream) {
   const int gmax = [&] { const char* e = getenv("TC_TB_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : cus; }();
   const int rounds = (a.tiles + gmax - 1) / gmax;
   const int grid = (a.tiles + rounds - 1) / rounds;
-  hipLaunchKernelGGL(tb_fused_kernel, dim3((unsigned)grid), dim3(TB_THREADS), 0, reinterpret_cast<hipStream_t>(stream), a);
+  if (a.abl & 8) hipLaunchKernelGGL(tb_fused_kernel<true>, dim3((unsigned)grid), dim3(TB_THREADS), 0, reinterpret_cast<hipStream_t>(stream), a);
+  else hipLaunchKernelGGL(tb_fused_kernel<false>, dim3((unsigned)grid), dim3(TB_THREADS), 0, reinterpret_cast<hipStream_t>(stream), a);
   TC_LAUNCH_CHECK();
   return TC_OK;
 }
