@@ -89,6 +89,49 @@ def test_unet_full_size_shared_cfg_prefix(full_model, golden, inp):
 
 
 @pytest.mark.timeout(1500)
+def test_unet_full_size_guided_passes_on_streams(full_model, golden, inp):
+    """TC_CFG_STREAMS=1 (UNetModel._forward_branches): behind the shared prefix the two guided passes are two batch-1
+    walks on their own HIP streams.  Against the batch-2 walk (another bf16 realisation: other tile families at half the
+    rows) and the fp32 oracle; then through apply_model_multi, where the fork / join is captured into the hipGraph --
+    eager call, capturing call and two replays must agree bit for bit (a pass reading a tensor of the other stream too
+    early, or K/V projected behind the fork, would show here)."""
+    un = full_model.model.diffusion_model
+    ctx2 = torch.cat([inp["cond"], inp["uncond"]]).to(DEV)
+    x, cc, fs = inp["x_T"].to(DEV), inp["c_concat"].to(DEV), inp["fs"].to(DEV)
+    ts = torch.tensor([fc.UNET_T], device=DEV)
+    with torch.no_grad():
+        shared = un(None, ts, context=ctx2, fs=fs, x_parts=[x, cc], replicas=2).clone()
+        un.reset_conditioning()
+        outs = un(None, ts, context=ctx2, fs=fs, x_parts=[x, cc], replicas=2, branches=True)
+        outs = [o.clone() for o in outs]
+        again = un(None, ts, context=ctx2, fs=fs, x_parts=[x, cc], replicas=2, branches=True)
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(golden["unet_y"])
+    e = rel_l2(outs[0].cpu(), ref)
+    d = [rel_l2(outs[i][0], shared[i]) for i in range(2)]
+    print(f"full-size UNet, guided passes on streams: cond pass vs oracle {e:.3e}; vs the batch-2 walk {d[0]:.3e} / {d[1]:.3e}")
+    assert len(outs) == 2 and all(o.shape == (1, *shared.shape[1:]) and torch.isfinite(o).all() for o in outs)
+    assert e <= UNET_REL and max(d) <= 2e-2
+    assert all(torch.equal(a, b) for a, b in zip(outs, again))             # deterministic across calls (no race)
+
+    cond = {"c_crossattn": [inp["cond"].to(DEV)], "c_concat": [cc]}
+    uc = {"c_crossattn": [inp["uncond"].to(DEV)], "c_concat": [cc]}
+    old = (full_model.cfg_streams, full_model.use_hipgraph, full_model._cfg_state)
+    full_model.cfg_streams, full_model.use_hipgraph, full_model._cfg_state = True, True, None
+    try:
+        with torch.no_grad():
+            runs = [[o.clone() for o in full_model.apply_model_multi(x, ts, [cond, uc], fs=fs)] for _ in range(4)]
+        torch.cuda.synchronize()
+        assert full_model._cfg_state["graph"] is not None
+        for r in runs[1:]:
+            assert torch.equal(r[0], runs[0][0]) and torch.equal(r[1], runs[0][1])
+        assert torch.equal(runs[0][0], outs[0]) and torch.equal(runs[0][1], outs[1])
+    finally:
+        full_model.cfg_streams, full_model.use_hipgraph, full_model._cfg_state = old
+        full_model.reset_conditioning()
+
+
+@pytest.mark.timeout(1500)
 @pytest.mark.parametrize("fp8", [None, "linear"])
 def test_ddim3_full_size_vs_oracle(full_model, golden, inp, fp8):
     """3-step CFG-7.5 DDIM (rescale 0.7, eta 1, trailing) with injected noise: batched-CFG B=2 UNet calls,

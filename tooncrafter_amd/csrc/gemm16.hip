@@ -16,7 +16,7 @@
 // Epilogue: each wave transposes its accumulators through a private 5 KiB fp32 slab, one 16-row tile row at a
 // time, and finishes on 16-byte row vectors (bias / row bias / activation / residual / store).  GEGLU layers
 // (weights packed per 32 columns) stay on the 128x128 / 256x320 kernels.
-#include "gemm_common.h"
+#include "gemm_persist.h"
 
 #include <stdlib.h>
 
@@ -37,7 +37,23 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 // v % 10) in EVERY pass, so a lane keeps one accumulator set per q (3 x 16 registers) and the walk of the plain
 // epilogue stays as it is (a first version pinned lanes to column groups -- 60 active lanes, three row steps per pass --
 // and cost the convolutions more than GroupNorm saved: +0.4 ms per forward against -0.3 ms).
-template <int GATHER, bool PIPE, bool STATS>
+// ABL (TC_G16_ABLATE, timing builds of the 3x3 gather only -- the results are WRONG): 1 = the A tile is requested for
+// the dx = -1 tap of each kernel row only (the L2->LDS traffic a slab shared by the three dx taps would have), 2 = no A
+// requests, 3 = no W requests, 4 = no requests at all (MFMAs + fragment reads + epilogue)
+// ILV (TC_G16_ILV): the tile requests of the K loop issued ONE OR TWO AT A TIME between the MFMAs instead of as a burst
+// of ten per wave in front of them.  Why: a wave cannot issue MFMAs while its LDS-DMA instructions queue for the CU's
+// address unit (~23 clk per 1 KiB piece with all eight waves streaming, scripts/probes/load_probe.hip), so the burst is a
+// phase of ~900 clk per block and K-step in which the block's four waves compute nothing -- loads-only 0.77 us and
+// MFMAs-only 0.99 us per K-step pair ADD to the measured 1.63 us instead of overlapping (profiles/r04_g16_ablate.txt).
+//   1 = the plain loop (request step k + 1, compute step k, wait, barrier) with the requests spread over the first half
+//       of the step's MFMAs;
+//   2 = a software pipeline over two LDS stages with TWO fragment sets: per K-step [fragments of the second K-slice |
+//       25 MFMAs of the first | wait: own reads done + own pieces of step k + 1 landed | barrier | fragments of step
+//       k + 1's first K-slice | 25 MFMAs of the second with the ten requests of step k + 2 between them] -- a request
+//       has half a step to land, a fragment read a quarter.
+// Requests come from inline asm (gemm_persist.h: g8_dma16): hipcc neither reorders them nor guards fragment reads of
+// the other stage with vmcnt(0).  Same MFMA order per accumulator as the plain loop: bit-identical results.
+template <int GATHER, bool PIPE, bool STATS, int ABL = 0, int ILV = 0>
 __global__ __launch_bounds__(256, 2) void gemm16_kernel(const TcGemmParams p, const int order) {
   __shared__ __attribute__((aligned(1024))) char smem[2 * T16_STAGE];
 
@@ -78,10 +94,14 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(const TcGemmParams p, co
     const uint32_t kill = (k_ragged && (k0 + chunk * 8 >= p.k)) ? TC_OOB : 0u;
     char* sa = smem + stage * T16_STAGE + wave_u * 1024;
     char* sb = sa + T16_BM * TC_BK * 2;
+    if (ABL != 3 && ABL != 4) {
 #pragma unroll
-    for (int i = 0; i < T16_R; ++i) glds16(w_rsrc, sb + i * 4096, b_voff[i] | kill, (uint32_t)k0 * 2u);
+      for (int i = 0; i < T16_R; ++i) glds16(w_rsrc, sb + i * 4096, b_voff[i] | kill, (uint32_t)k0 * 2u);
+    }
+    if (ABL == 0 || (ABL == 1 && ((k0 / p.cin) % 3) == 0)) {
 #pragma unroll
-    for (int i = 0; i < T16_R; ++i) glds16(a_rsrc, sa + i * 4096, a_voff[i] | kill, a_soff);
+      for (int i = 0; i < T16_R; ++i) glds16(a_rsrc, sa + i * 4096, a_voff[i] | kill, a_soff);
+    }
   };
 
   f32x4_t acc[T16_NT][T16_NT];
@@ -124,7 +144,128 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(const TcGemmParams p, co
   };
 
   const int nk = (p.k + TC_BK - 1) / TC_BK;
-  if (PIPE) {
+  if constexpr (ILV != 0) {
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;     // LDS byte address of smem
+    const g8_srd_t w_srd = g8_make_srd(reinterpret_cast<const bf16_t*>(p.w) + bz * p.stride_w, tc_w_extent(p));
+    // the slim request state of the persistent kernels (per row a byte offset and a tap mask; stride-1 3x3 only: the
+    // host keeps stride 2 / fused upsample on the plain loop) -- AGather's generic path costs 15 more registers
+    G8Gather<GATHER, 32, T16_R> sg;
+    sg.init(p, tile_m * T16_BM, lrow, chunk);
+    const g8_srd_t a_srd = g8_make_srd(reinterpret_cast<const bf16_t*>(p.a) + bz * p.stride_a + sg.row_lo * p.lda,
+                                       tc_a_extent(p) - sg.row_lo * p.lda * 2);
+    const int tpt = GATHER == TC_GATHER_LINEAR ? 1 : p.cin / TC_BK;     // K-tiles per tap (cin % 64 == 0: host)
+    const uint32_t tap_magic = (65536u + tpt - 1) / tpt;                // kb / tpt as a multiply-high, exact for kb < 1024
+    // the ten requests of one K-step: pieces 0..4 = W row passes, 5..9 = A row passes
+    uint32_t r_avoff[T16_R], r_asoff = 0, r_wsoff = 0, r_kill = 0, r_dst = 0;
+    auto prep = [&](int kb, int stage) {
+      const int k0 = kb * TC_BK;
+      int tap = 0;
+      uint32_t delta = 0;
+      r_asoff = (uint32_t)k0 * 2u;
+      if (GATHER != TC_GATHER_LINEAR) {
+        tap = (int)(((uint32_t)kb * tap_magic) >> 16);
+        r_asoff = (uint32_t)(k0 - tap * p.cin) * 2u;
+        if (GATHER == TC_GATHER_CONV3x3) {
+          const int ty = (tap * 11) >> 5;                               // tap / 3 for tap < 9
+          delta = (uint32_t)(((ty - 1) * p.w_in + (tap - ty * 3 - 1)) * p.lda * 2);
+        } else {
+          delta = (uint32_t)((tap - 1) * p.h_out * p.w_out * p.lda * 2);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < T16_R; ++q) r_avoff[q] = sg.voff(q, tap, delta);
+      r_kill = (k_ragged && (k0 + chunk * 8 >= p.k)) ? TC_OOB : 0u;
+      r_wsoff = (uint32_t)k0 * 2u;
+      r_dst = lds0 + (uint32_t)(stage * T16_STAGE + wave_u * 1024);
+    };
+    auto issue = [&](auto Q_) {
+      constexpr int q = decltype(Q_)::value;
+      if constexpr (q < T16_R) g8_dma16(w_srd, r_dst + T16_BM * TC_BK * 2 + q * 4096, b_voff[q] | r_kill, r_wsoff);
+      else g8_dma16(a_srd, r_dst + (q - T16_R) * 4096, r_avoff[q - T16_R] | r_kill, r_asoff);
+    };
+    auto issue_all = [&]() {
+      issue(ic<0>{}); issue(ic<1>{}); issue(ic<2>{}); issue(ic<3>{}); issue(ic<4>{});
+      issue(ic<5>{}); issue(ic<6>{}); issue(ic<7>{}); issue(ic<8>{}); issue(ic<9>{});
+    };
+    auto issue_pair = [&](auto I_) {                    // the two pieces that go behind MFMA row i
+      constexpr int i = decltype(I_)::value;
+      issue(ic<2 * i>{});
+      issue(ic<2 * i + 1>{});
+    };
+    auto read_frags = [&](int stage, int ks, bf16x8 (&af)[T16_NT], bf16x8 (&bf)[T16_NT]) {
+      const char* sa = smem + stage * T16_STAGE;
+      const char* sb = sa + T16_BM * TC_BK * 2;
+      const int ca = ((ks * 4 + fq) ^ a_sw) << 4;
+      const int cb = ((ks * 4 + fq) ^ b_sw) << 4;
+#pragma unroll
+      for (int i = 0; i < T16_NT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + a_off[i] + ca);
+#pragma unroll
+      for (int j = 0; j < T16_NT; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(sb + b_off[j] + cb);
+    };
+    auto mma_row = [&](auto I_, const bf16x8 (&af)[T16_NT], const bf16x8 (&bf)[T16_NT]) {
+      constexpr int i = decltype(I_)::value;
+#pragma unroll
+      for (int j = 0; j < T16_NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    };
+    prep(0, 0);
+    issue_all();
+    if constexpr (ILV == 1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      g8_barrier();
+      for (int kb = 0; kb < nk; ++kb) {
+        const int st = kb & 1;
+        const bool more = kb + 1 < nk;
+        if (more) prep(kb + 1, st ^ 1);
+        bf16x8 af[T16_NT], bf[T16_NT];
+        read_frags(st, 0, af, bf);
+        auto row0 = [&](auto I_) {
+          mma_row(I_, af, bf);
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) issue_pair(I_);
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        row0(ic<0>{}); row0(ic<1>{}); row0(ic<2>{}); row0(ic<3>{}); row0(ic<4>{});
+        read_frags(st, 1, af, bf);
+        mma_row(ic<0>{}, af, bf); mma_row(ic<1>{}, af, bf); mma_row(ic<2>{}, af, bf); mma_row(ic<3>{}, af, bf); mma_row(ic<4>{}, af, bf);
+        __builtin_amdgcn_sched_barrier(0);           // (hipcc otherwise sinks the MFMAs below the wait: it is no memory operation to them)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        g8_barrier();
+      }
+    } else {
+      if (nk > 1) {
+        prep(1, 1);
+        issue_all();
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * T16_R) : "memory");       // step 0 has landed, step 1 may be in flight
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      g8_barrier();
+      bf16x8 af0[T16_NT], bf0[T16_NT], af1[T16_NT], bf1[T16_NT];
+      read_frags(0, 0, af0, bf0);
+      for (int kb = 0; kb < nk; ++kb) {
+        const int st = kb & 1;
+        const bool more2 = kb + 2 < nk;
+        // first K-slice: its fragments were read during the previous step; the second slice's are read beside its MFMAs
+        read_frags(st, 1, af1, bf1);
+        mma_row(ic<0>{}, af0, bf0); mma_row(ic<1>{}, af0, bf0); mma_row(ic<2>{}, af0, bf0); mma_row(ic<3>{}, af0, bf0); mma_row(ic<4>{}, af0, bf0);
+        // own reads of stage st complete; own pieces of step kb + 1 (requested half a step ago) landed
+        __builtin_amdgcn_sched_barrier(0);           // (hipcc otherwise sinks the MFMAs below the wait: it is no memory operation to them)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        g8_barrier();                                  // -> stage st is free, stage st ^ 1 is complete, for every wave
+        if (more2) prep(kb + 2, st);
+        read_frags(st ^ 1, 0, af0, bf0);              // (unconditional: in the last step it reads a dead stage and nothing uses it;
+                                                      //  under a branch hipcc's waitcnt pass makes the MFMAs below wait for these reads)
+        auto row1 = [&](auto I_) {
+          mma_row(I_, af1, bf1);
+          __builtin_amdgcn_sched_barrier(0);
+          if (more2) issue_pair(I_);
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        row1(ic<0>{}); row1(ic<1>{}); row1(ic<2>{}); row1(ic<3>{}); row1(ic<4>{});
+      }
+    }
+    __syncthreads();                               // the epilogue slabs reuse the stage buffers
+  } else if (PIPE) {
     load_tile(0, 0);
     if (nk > 1) load_tile(1, 1);
     for (int kb = 0; kb < nk; ++kb) {
@@ -298,6 +439,32 @@ int tc_gemm_tile16_try(const TcGemmParams& p, int batch, hipStream_t s, bool dry
   // TC_GEMM_PIPE = 2 only: on this tile the deeper prefetch measured 0.97-1.02x (profiles/r03_pipe_bench.txt) -- two
   // blocks of 80 KiB per CU already overlap each other's load latency -- so the default keeps the plain loop
   const bool pipe = [] { const char* e = getenv("TC_GEMM_PIPE"); return e && e[0] == '2'; }();      // per call (A/B runs)
+  const int abl = [] { const char* e = getenv("TC_G16_ABLATE"); return e ? atoi(e) : 0; }();             // per call (timing runs)
+  if (abl >= 1 && abl <= 4 && p.gather == TC_GATHER_CONV3x3 && !stats) {
+    if (abl == 1) hipLaunchKernelGGL((gemm16_kernel<TC_GATHER_CONV3x3, false, false, 1>), grid, block, 0, s, p, order);
+    if (abl == 2) hipLaunchKernelGGL((gemm16_kernel<TC_GATHER_CONV3x3, false, false, 2>), grid, block, 0, s, p, order);
+    if (abl == 3) hipLaunchKernelGGL((gemm16_kernel<TC_GATHER_CONV3x3, false, false, 3>), grid, block, 0, s, p, order);
+    if (abl == 4) hipLaunchKernelGGL((gemm16_kernel<TC_GATHER_CONV3x3, false, false, 4>), grid, block, 0, s, p, order);
+    return 1;
+  }
+  // TC_G16_ILV = 0 (default) | 1 | 2: requests between the MFMAs (see the kernel header); read per call (A/B runs)
+  const int ilv = [] { const char* e = getenv("TC_G16_ILV"); return e ? atoi(e) : 0; }();
+  const bool ilv_ok = (p.gather == TC_GATHER_LINEAR || (p.cin % TC_BK) == 0) && p.k < 1024 * TC_BK &&
+                      (p.gather != TC_GATHER_CONV3x3 || (p.stride == 1 && !p.upsample && p.pad == 1));
+  if ((ilv == 1 || ilv == 2) && !stats && ilv_ok) {
+#define TC_LAUNCH16_ILV(G)                                                                                       \
+  do {                                                                                                           \
+    if (ilv == 1) hipLaunchKernelGGL((gemm16_kernel<G, false, false, 0, 1>), grid, block, 0, s, p, order);       \
+    else hipLaunchKernelGGL((gemm16_kernel<G, false, false, 0, 2>), grid, block, 0, s, p, order);                \
+  } while (0)
+    switch (p.gather) {
+      case TC_GATHER_LINEAR: TC_LAUNCH16_ILV(TC_GATHER_LINEAR); break;
+      case TC_GATHER_CONV3x3: TC_LAUNCH16_ILV(TC_GATHER_CONV3x3); break;
+      default: TC_LAUNCH16_ILV(TC_GATHER_CONVT3); break;
+    }
+#undef TC_LAUNCH16_ILV
+    return 1;
+  }
 #define TC_LAUNCH16(G)                                                                              \
   do {                                                                                              \
     if (stats) hipLaunchKernelGGL((gemm16_kernel<G, false, true>), grid, block, 0, s, p, order);    \

@@ -28,17 +28,17 @@ __device__ __forceinline__ void g8_tile_of(int id, int tiles_m, int tiles_n, int
 
 // Request state of one tile's A rows: what AGather (gemm_common.h) keeps, minus the generic 3x3 path (stride 2 /
 // fused upsample stay on the 4-wave kernels): per row a byte offset from the tile's lowest source row and a mask of
-// the taps that fall inside the image.  Rows are lrow + STEP q, q = 0..3.
-template <int GATHER, int STEP = 64>
+// the taps that fall inside the image.  Rows are lrow + STEP q, q = 0..R-1 (gemm8: 4 x 64; gemm16's interleaved loop: 5 x 32).
+template <int GATHER, int STEP = 64, int R = 4>
 struct G8Gather {
-  uint32_t base[4];
-  uint32_t vbits[4];
+  uint32_t base[R];
+  uint32_t vbits[R];
   int64_t row_lo;
 
   __device__ __forceinline__ void init(const TcGemmParams& p, int tile_row0, int lrow, int chunk) {
     row_lo = tc_tile_row_lo<GATHER>(p, tile_row0);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < R; ++q) {
       const int mm = tile_row0 + lrow + STEP * q;
       const bool ok = mm < p.m;
       const int mc = ok ? mm : 0;

@@ -68,6 +68,10 @@ class ContextCache:
     def matches(self, context: torch.Tensor, t: int) -> bool:
         return self.shape == tuple(context.shape) and self.t == t and self.text_rows.device == context.device
 
+    def branch(self, k: int, b: int) -> "CtxBranch":
+        """Samples [k b, (k + 1) b) of this conditioning: what pass k of a guided step attends to (CfgShare branches)."""
+        return CtxBranch(self, k, b)
+
     def refresh(self, context: torch.Tensor):
         """(Re)load the token rows and recompute every cached K/V projection in place."""
         ctx = context.detach()
@@ -79,6 +83,21 @@ class ContextCache:
             module.project_context(self, kv_text, kv_img)
         self.key = SourceKey([context])
         self.epoch = PackedModule.graph_epoch()
+
+
+class CtxBranch:
+    """A batch slice of a ContextCache (same token geometry; K/V are row slices of the parent's projections)."""
+
+    def __init__(self, parent: ContextCache, k: int, b: int):
+        if (k + 1) * b > parent.b:
+            raise ValueError(f"context holds {parent.b} samples: no slice {k} of {b}")
+        self.parent, self.k, self.b, self.t = parent, k, b, parent.t
+        self.text_len, self.img_len, self.img_per_frame = parent.text_len, parent.img_len, parent.img_per_frame
+        self.img_rows = parent.img_rows
+
+    def rows_of(self, kv: torch.Tensor) -> torch.Tensor:
+        per = kv.shape[0] // self.parent.b                      # token rows per sample (77; 16 T or the shared image tokens)
+        return kv[self.k * self.b * per:(self.k + 1) * self.b * per]
 
 
 class GEGLU(nn.Module):
@@ -185,12 +204,15 @@ class CrossAttention(PackedModule):
             kv_img = ops.gemm(ctx.img_rows, pk["wkv_ip"], out=kv_img)
         return kv_text, kv_img
 
-    def context_kv(self, ctx: ContextCache):
-        hit = ctx.kv.get(id(self))
+    def context_kv(self, ctx):
+        root = getattr(ctx, "parent", ctx)                      # a CtxBranch reads row slices of its parent's K/V
+        hit = root.kv.get(id(self))
         if hit is None:
-            kv_text, kv_img = self.project_context(ctx)
-            hit = ctx.kv[id(self)] = (self, kv_text, kv_img)
-        return hit[1], hit[2]
+            kv_text, kv_img = self.project_context(root)
+            hit = root.kv[id(self)] = (self, kv_text, kv_img)
+        if root is ctx:
+            return hit[1], hit[2]
+        return ctx.rows_of(hit[1]), None if hit[2] is None else ctx.rows_of(hit[2])
 
     def forward_cross(self, x_norm, residual, act: Act, ctx: ContextCache, ln=None):
         pk = self.pk
@@ -286,11 +308,14 @@ class BasicTransformerBlock(PackedModule):
         """`share` (first block of the UNet's first spatial transformer under batched guidance): x / act arrive at the
         single-copy batch; the guided passes part ways at the cross-attention, so the rows are repeated in front of it
         and (x, expanded act) is returned."""
-        h, ln = self._pre(x, 1, self.attn1.pk["wqkv"], "qkv")
-        x = self.attn1.forward_spatial_self(h, x, act, ln=ln)
+        def self_attn(x=x):
+            h, ln = self._pre(x, 1, self.attn1.pk["wqkv"], "qkv")
+            return self.attn1.forward_spatial_self(h, x, act, ln=ln)
+        x = self_attn() if share is None else share.cached(("attn1", id(self)), self_attn)
         if share is not None:
-            x, act = ops.repeat_rows(x, share.n), share.expand(act)
-            share.done = True
+            if not share.branches:
+                x, act = ops.repeat_rows(x, share.n), share.expand(act)
+            share.split(x)                                               # branches: every pass goes on alone, at batch b
         h, ln = self._pre(x, 2, self.attn2.pk["wq"], "q")
         x = self.attn2.forward_cross(h, x, act, ctx, ln=ln)
         h, ln = self._pre(x, 3, self.ff.pk["w1"], "ff")
@@ -341,8 +366,11 @@ class SpatialTransformer(PackedModule):
 
     def forward(self, act: Act, ctx: ContextCache, share: CfgShare = None) -> Act:
         pk = self.pk
-        h = ops.groupnorm(act.rows, pk["gn_g"], pk["gn_b"], samples=act.frames, rows=act.hw, eps=1e-6)
-        h = ops.gemm(h, pk["wi"], pk["bi"])
+
+        def proj_in():
+            h = ops.groupnorm(act.rows, pk["gn_g"], pk["gn_b"], samples=act.frames, rows=act.hw, eps=1e-6)
+            return ops.gemm(h, pk["wi"], pk["bi"])
+        h = proj_in() if share is None else share.cached(("proj_in", id(self)), proj_in)
         for blk in self.transformer_blocks:
             if share is not None and not share.done:
                 h, act = blk.forward_spatial(h, act, ctx, share)        # act: now the n-fold batch (proj_out's residual)

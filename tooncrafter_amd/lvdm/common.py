@@ -48,16 +48,48 @@ class CfgShare:
     timestep and fps -- they differ only through the cross-attention context.  Everything in front of the first
     cross-attention (input conv, the initial temporal transformer, the first ResBlock + temporal convolutions, the first
     spatial self-attention) therefore computes n identical copies: it runs ONCE at batch b and is repeated where the
-    paths part.  Exact (the identical copies were bit-identical to begin with: no cross-sample term anywhere)."""
+    paths part.  Exact (the identical copies were bit-identical to begin with: no cross-sample term anywhere).
 
-    def __init__(self, n: int, emb1: torch.Tensor):
-        self.n, self.emb1, self.embn, self.done = n, emb1, ops.repeat_rows(emb1, n), False
+    `branches=True` (TC_CFG_STREAMS=1, UNetModel._forward_branches): what follows the shared part is not one batch-(n b)
+    pass but n batch-b passes, each on its own HIP stream -- the passes are independent from the first cross-attention
+    on, so one pass's kernels fill the CUs another's leave idle (launch ramps and tails, the 64-block GroupNorms, the
+    low-resolution levels).  Pass 0 RECORDS what it computes in front of the split (`cached`), passes 1.. REPLAY those
+    tensors instead of computing them and wait for the event pass 0 recorded at the split."""
+
+    def __init__(self, n: int, emb1: torch.Tensor, branches: bool = False):
+        self.n, self.emb1, self.done, self.branches = n, emb1, False, branches
+        self.embn = emb1 if branches else ops.repeat_rows(emb1, n)
+        self.memo, self.replay, self.fork = {}, False, None
 
     def emb(self) -> torch.Tensor:
         return self.embn if self.done else self.emb1
 
     def expand(self, act: "Act") -> "Act":
         return Act(ops.repeat_rows(act.rows, self.n), act.b * self.n, act.t, act.h, act.w)
+
+    # ---- branches mode
+    def begin(self, k: int):
+        """Start pass k: pass 0 records the shared part, the others replay it."""
+        self.replay, self.done = k > 0, False
+
+    def cached(self, key, fn):
+        """Result of `fn()` for a piece of the network that may lie in front of the split.  Plain mode: just `fn()`.
+        Branches mode: pass 0 keeps the result if the split has not happened by the time `fn` returns (a piece that
+        CONTAINS the split is not kept: its inner pieces are); the other passes take a kept result instead of computing."""
+        if not self.branches:
+            return fn()
+        if self.replay and key in self.memo:
+            return self.memo[key]
+        v = fn()
+        if not self.replay and not self.done:
+            self.memo[key] = v
+        return v
+
+    def split(self, x: torch.Tensor):
+        """The point where the passes part (behind the first spatial self-attention).  Pass 0 marks it on its stream."""
+        if self.branches and not self.replay and x.is_cuda:
+            self.fork = torch.cuda.current_stream(x.device).record_event()
+        self.done = True
 
 
 class SourceKey:

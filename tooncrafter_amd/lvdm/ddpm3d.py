@@ -171,6 +171,9 @@ class LatentDiffusion(DDPM):
         self._cfg_state = None
         self.use_hipgraph = os.environ.get("TC_HIPGRAPH", "1") != "0"
         self.cfg_share = os.environ.get("TC_CFG_SHARE", "1") != "0"
+        # the guided passes behind the shared prefix as concurrent batch-b walks on their own HIP streams
+        # (openaimodel3d.UNetModel._forward_branches) instead of one batch-(n b) walk
+        self.cfg_streams = os.environ.get("TC_CFG_STREAMS", "0") == "1"
 
     def _instantiate_cond_stage(self, config):
         model = instantiate_from_config(config)
@@ -231,7 +234,7 @@ class LatentDiffusion(DDPM):
         share = n > 1 and self.cfg_share and all(
             len(c["c_concat"]) == len(conds[0]["c_concat"]) and all(a is b0 for a, b0 in zip(c["c_concat"], conds[0]["c_concat"]))
             for c in conds[1:])
-        shape_sig = (n, tuple(x_noisy.shape), x_noisy.device, share)
+        shape_sig = (n, tuple(x_noisy.shape), x_noisy.device, share, share and self.cfg_streams)
         st = self._cfg_state
         unet = self.model.diffusion_model
         if st is None or st["key"] is None or st["shape_sig"] != shape_sig or not st["key"].same(cond_t):
@@ -259,14 +262,16 @@ class LatentDiffusion(DDPM):
             st["x2"][k * b:(k + 1) * b].copy_(x_noisy)
             st["ts2"][k * b:(k + 1) * b].copy_(t)
 
+        branches = share and self.cfg_streams
+
         def fwd():
             return unet(None, st["ts2"], context=st["ctx2"], fs=st["fs2"], x_parts=[st["x2"], st["cc2"]],
-                        replicas=n if share else 1)
+                        replicas=n if share else 1, branches=branches)
 
         if self.use_hipgraph and x_noisy.is_cuda:
             # a captured graph replays the kernels and the packed-weight pointers it recorded: new weights
             # (load_state_dict / invalidate) or another MXFP8 routing since capture make it stale
-            sig = (PackedModule.graph_epoch(), getattr(ops.backend(), "fp8", None))
+            sig = (PackedModule.graph_epoch(), getattr(ops.backend(), "fp8", None), branches)
             if st["graph"] is not None and st.get("graph_sig") != sig:
                 st["graph"], st["calls"] = None, 0
             if st["graph"] is None and st["calls"] >= 1:             # first call ran eagerly (warm caches)
@@ -282,7 +287,7 @@ class LatentDiffusion(DDPM):
         else:
             out = fwd()
         st["calls"] += 1
-        return [out[k * b:(k + 1) * b] for k in range(n)]
+        return list(out) if isinstance(out, (list, tuple)) else [out[k * b:(k + 1) * b] for k in range(n)]
 
     def reset_conditioning(self):
         """Clip boundary (called by the samplers at the start of `sample()`, like one iteration of the

@@ -169,17 +169,15 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
     def forward(self, act: Act, emb_all, ctx: Optional[ContextCache] = None, share=None) -> Act:
         """`share` (common.CfgShare): under batched guidance the layers in front of the first cross-attention see the
         single-copy batch; `emb_all` is then taken from it (single-copy rows before the split, n-fold after)."""
-        for layer in self:
-            if isinstance(layer, ResBlock):
-                act = layer(act, emb_all if share is None else share.emb())
-            elif isinstance(layer, SpatialTransformer):
-                act = layer(act, ctx, share if share is not None and not share.done else None)
-            elif isinstance(layer, TemporalTransformer):
-                act = layer(act)
-            elif isinstance(layer, InputConv):
-                act = layer(act)
-            else:
-                act = layer(act)
+        for j, layer in enumerate(self):
+            def run(layer=layer, act=act):
+                if isinstance(layer, ResBlock):
+                    return layer(act, emb_all if share is None else share.emb())
+                if isinstance(layer, SpatialTransformer):
+                    return layer(act, ctx, share if share is not None and not share.done else None)
+                return layer(act)                      # TemporalTransformer, InputConv, Downsample, Upsample
+            # in front of the split a layer's result is the same for every guided pass (CfgShare.cached)
+            act = run() if share is None or share.done else share.cached(("layer", id(self), j), run)
         return act
 
 
@@ -351,14 +349,16 @@ class UNetModel(PackedModule):
         return ops.gemm(semb, pk["emb_w"], pk["emb_b"], out_f32=True)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, timesteps, context=None, features_adapter=None, fs=None, x_parts=None, replicas=1, **kwargs):
+    def forward(self, x, timesteps, context=None, features_adapter=None, fs=None, x_parts=None, replicas=1,
+                branches=False, **kwargs):
         """x: (B, in_channels, T, H, W) fp32 (or `x_parts` = [x, c_concat] to skip the torch.cat of
         the hybrid conditioning); timesteps: [B] long; context: (B, 77+16T, Cc); fs: [B] long.
         Extra kwargs are swallowed like the reference does (openaimodel3d.py:548).
 
         `replicas` = n > 1 (batched classifier-free guidance, ddpm3d.apply_model_multi): x / timesteps / fs describe ONE
         copy of batch b, `context` all n * b; the result has batch n * b as if the copy had been repeated n times, but the
-        layers in front of the first cross-attention run once (common.CfgShare)."""
+        layers in front of the first cross-attention run once (common.CfgShare).  With `branches` the n passes go their
+        own ways behind that point, each at batch b on its own HIP stream, and the result is the LIST of their outputs."""
         if features_adapter is not None:
             raise NotImplementedError("features_adapter is unused by the inference path")
         parts = x_parts if x_parts is not None else [x]
@@ -370,13 +370,19 @@ class UNetModel(PackedModule):
         act = Act(rows, b, t, hh, ww)
         ctx = self.context_cache(context, t)
         emb_all = self._embedding(timesteps, fs, b)
+        if replicas > 1 and branches:
+            return self._forward_branches(act, emb_all, ctx, replicas)
         share = CfgShare(replicas, emb_all) if replicas > 1 else None
+        return self._body(act, emb_all, ctx, share)
 
+    def _body(self, act: Act, emb_all, ctx, share: Optional[CfgShare]):
+        """Input blocks -> middle -> output blocks -> out conv, from the rows of the latent to the (B, C, T, H, W) result."""
+        t = act.t
         hs = []
         for i, module in enumerate(self.input_blocks):
             act = module(act, emb_all, ctx, share)
             if i == 0 and self.addition_attention:
-                act = self.init_attn(act, emb_all, ctx)            # a TemporalTransformer: no context, no embedding
+                act = self.init_attn(act, emb_all, ctx, share)     # a TemporalTransformer: no context, no embedding
             hs.append(act)
         if share is not None:
             if not share.done:
@@ -394,3 +400,37 @@ class UNetModel(PackedModule):
         geom, _, _ = _conv_geom(act, act.c)
         y = ops.gemm(h, pk["ow"], pk["ocb"], conv=geom, out_f32=True)
         return ops.rows_to_nchw(y, c=self.out_channels, b=act.b, t=t, h=act.h, w=act.w)
+
+    def _forward_branches(self, act: Act, emb_all, ctx: ContextCache, n: int):
+        """The n guided passes as n batch-b walks of the network that share what precedes the first cross-attention:
+        pass 0 runs on the current stream and records the shared tensors; passes 1.. replay them and run on side streams
+        that wait for the split point of pass 0 -- under hipGraph capture this becomes a fork / join inside the graph.
+        The shared tensors live until every pass has been enqueued and the current stream waits for the side streams
+        before anything is released or consumed, so no cross-stream lifetime bookkeeping is needed."""
+        if getattr(self, "_cross", None) is None:
+            self._cross = [m for m in self.modules() if getattr(m, "is_self", True) is False]
+        for m in self._cross:                                      # K/V of every cross-attention exist BEFORE the fork (a first
+            m.context_kv(ctx)                                      # call would otherwise project them mid-pass 0, on a stream
+                                                                   # the other passes do not wait for)
+        share = CfgShare(n, emb_all, branches=True)
+        cuda = act.rows.is_cuda
+        main = torch.cuda.current_stream(act.rows.device) if cuda else None
+        side = self._side_streams(n - 1, act.rows.device) if cuda else []
+        outs = []
+        for k in range(n):
+            share.begin(k)
+            if k == 0 or not cuda:
+                outs.append(self._body(act, emb_all, ctx.branch(k, act.b), share))
+            else:
+                side[k - 1].wait_event(share.fork)
+                with torch.cuda.stream(side[k - 1]):
+                    outs.append(self._body(act, emb_all, ctx.branch(k, act.b), share))
+        for s in side:
+            main.wait_stream(s)
+        return outs
+
+    def _side_streams(self, n: int, device):
+        st = getattr(self, "_streams", None)
+        if st is None or len(st) < n or st[0].device != device:
+            st = self._streams = [torch.cuda.Stream(device=device) for _ in range(n)]
+        return st[:n]
