@@ -17,16 +17,18 @@ def timeit(fn, iters=20, reps=3):
         e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) / iters)
     return min(ts)
 
+ARMS = [("plain", 0, 0), ("loop2", 2, 0), ("tall", 0, 2), ("tall+loop1", 1, 2), ("tall+loop2", 2, 2)]
+
 def ab(fn, flops, tag):
     r = {}
     for _ in range(2):
-        for v in ("0", "1", "2"):
-            os.environ["TC_G16_ILV"] = v
-            r.setdefault(v, []).append(timeit(fn))
-    os.environ["TC_G16_ILV"] = "0"
+        for name, ilv, tall in ARMS:
+            os.environ["TC_G16_ILV"], os.environ["TC_G16_TALL"] = str(ilv), str(tall)
+            r.setdefault(name, []).append(timeit(fn))
+    os.environ["TC_G16_ILV"] = os.environ["TC_G16_TALL"] = "0"
     t = {v: min(x) * 1e3 for v, x in r.items()}
-    print(f"{tag:34s} plain {t['0']:7.1f} us {flops / t['0'] / 1e6:7.1f} TF/s | loop 1 {t['1']:7.1f} us x{t['0'] / t['1']:5.3f} | "
-          f"loop 2 {t['2']:7.1f} us {flops / t['2'] / 1e6:7.1f} TF/s x{t['0'] / t['2']:5.3f}", flush=True)
+    print(f"{tag:34s} plain {t['plain']:7.1f} us {flops / t['plain'] / 1e6:7.1f} TF/s | " +
+          " | ".join(f"{n} {t[n]:7.1f} x{t['plain'] / t[n]:5.3f}" for n, _, _ in ARMS[1:]), flush=True)
 
 def conv(frames, h, w, cin, cout, tag, t3=False):
     x = torch.randn(frames * h * w, cin, device=dev).to(BF)

@@ -1,4 +1,5 @@
-"""The 160x160 GEMM's K loop with the tile requests BETWEEN the MFMAs (csrc/gemm16.hip: TC_G16_ILV = 1 | 2; reference call
+"""The 160x160 GEMM's K loop with the tile requests BETWEEN the MFMAs (csrc/gemm16.hip: TC_G16_ILV = 1 | 2) and its tall
+320 x 160 tile on eight waves (TC_G16_TALL; the third W pass half empty: its four pieces go to a dump area) -- reference call
 sites: nn.Linear / nn.Conv2d 3x3 / nn.Conv3d (3,1,1) of lvdm/modules/networks/openaimodel3d.py:154,179,255-266 and
 lvdm/modules/attention.py:415-442) against the fp32 statement of the operator (tests/emu_ops.py) and against the plain loop.
 
@@ -30,20 +31,24 @@ def emu():
     return EmuOps(round_bf16=True)
 
 
+ARMS = [(0, 0), (1, 0), (2, 0), (0, 2), (1, 2), (2, 2)]     # (TC_G16_ILV, TC_G16_TALL): loop x tile height (160 | 320 rows, 8 waves)
+
+
 def _arms(fn):
-    """fn() on the 160x160 kernel (forced) under the plain loop and under both interleaved loops."""
+    """fn() on the 160-column kernel (forced) under the plain loop and both interleaved loops, on both tile heights."""
     out = {}
-    for ilv in (0, 1, 2):
-        with env(TC_GEMM_TILE16=2, TC_G16_ILV=ilv, TC_GEMM_SPLITK=0, TC_GEMM8=0, TC_GEMM_WS=0):
-            out[ilv] = fn()
+    for ilv, tall in ARMS:
+        with env(TC_GEMM_TILE16=2, TC_G16_ILV=ilv, TC_G16_TALL=tall, TC_GEMM_SPLITK=0, TC_GEMM8=0, TC_GEMM_WS=0):
+            out[(ilv, tall)] = fn()
     torch.cuda.synchronize()
     return out
 
 
 def _same(out, ref, what):
-    check(out[0], ref, what)
-    assert torch.equal(out[1], out[0]), f"{what}: loop 1 differs bit-wise from the plain loop"
-    assert torch.equal(out[2], out[0]), f"{what}: loop 2 differs bit-wise from the plain loop"
+    base = out[(0, 0)]
+    check(base, ref, what)
+    for arm in ARMS[1:]:
+        assert torch.equal(out[arm], base), f"{what}: loop {arm[0]} / tall {arm[1]} differs bit-wise from the plain 160-row loop"
 
 
 @pytest.mark.parametrize("m,n,k", [(160, 160, 64), (320, 160, 128), (1000, 320, 192), (4096, 640, 2560), (5120, 1280, 320),
@@ -98,24 +103,24 @@ def test_strided_views_and_untouched_neighbours(hip, emu):
     w, bias = rnd(n, k, seed=42, scale=k ** -0.5), rnd(n, seed=43, dtype=torch.float32)
     res = rnd(m, 2 * n, seed=44)[:, n:]
     outs = {}
-    for ilv in (0, 1, 2):
+    for ilv, tall in ARMS:
         outbuf = torch.full((m + 300, 3 * n), 7.0, dtype=BF16, device="cuda")
-        with env(TC_GEMM_TILE16=2, TC_G16_ILV=ilv, TC_GEMM_SPLITK=0, TC_GEMM8=0, TC_GEMM_WS=0):
+        with env(TC_GEMM_TILE16=2, TC_G16_ILV=ilv, TC_G16_TALL=tall, TC_GEMM_SPLITK=0, TC_GEMM8=0, TC_GEMM_WS=0):
             hip.gemm(a, w, bias, residual=res, out=outbuf[:m, n:2 * n])
         torch.cuda.synchronize()
         assert float((outbuf[:m, :n] - 7).abs().max()) == 0 and float((outbuf[:m, 2 * n:] - 7).abs().max()) == 0
         assert float((outbuf[m:] - 7).abs().max()) == 0, "rows behind M were written"
-        outs[ilv] = outbuf[:m, n:2 * n].clone()
+        outs[(ilv, tall)] = outbuf[:m, n:2 * n].clone()
     _same(outs, emu.gemm(a, w, bias, residual=res), "gemm16 ilv strided A / C / residual")
 
 
-@pytest.mark.parametrize("ilv", [1, 2])
-def test_repeated_launches_are_bit_identical(hip, ilv):
-    """Race screen: 30 launches of a two-round problem (1024 tiles on 512 block slots), all identical."""
+@pytest.mark.parametrize("ilv,tall", ARMS[1:])
+def test_repeated_launches_are_bit_identical(hip, ilv, tall):
+    """Race screen: 30 launches of a two-round problem (1024 / 512 tiles on 512 / 256 block slots), all identical."""
     frames, h, w_, cin, n = 32, 40, 64, 320, 320
     conv = dict(kind="3x3", frames=frames, cin=cin, h_in=h, w_in=w_, h_out=h, w_out=w_, stride=1, upsample=False)
     a, w = rnd(frames * h * w_, cin, seed=61), rnd(n, 9 * cin, seed=62, scale=(9 * cin) ** -0.5)
-    with env(TC_GEMM_TILE16=2, TC_G16_ILV=ilv):
+    with env(TC_GEMM_TILE16=2, TC_G16_ILV=ilv, TC_G16_TALL=tall):
         first = hip.gemm(a, w, conv=conv)
         for _ in range(30):
             assert torch.equal(hip.gemm(a, w, conv=conv), first), "a launch differs: a tile was read before it landed"

@@ -53,9 +53,24 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 //       has half a step to land, a fragment read a quarter.
 // Requests come from inline asm (gemm_persist.h: g8_dma16): hipcc neither reorders them nor guards fragment reads of
 // the other stage with vmcnt(0).  Same MFMA order per accumulator as the plain loop: bit-identical results.
-template <int GATHER, bool PIPE, bool STATS, int ABL = 0, int ILV = 0>
-__global__ __launch_bounds__(256, 2) void gemm16_kernel(const TcGemmParams p, const int order) {
-  __shared__ __attribute__((aligned(1024))) char smem[2 * T16_STAGE];
+// WM = 4 (TC_G16_TALL): a 320 x 160 tile on EIGHT waves (4 x 2 of the same 80 x 80 wave tiles), one block per CU.  The W
+// tile is what a K-step pays for (without its requests the kernel runs at its MFMA-only time, without A's it does not:
+// profiles/r04_g16_ablate.txt); a tall block requests it once for twice the rows -- 60 KiB per K-step and CU instead of
+// 80, W's share halved -- and keeps the wave tile, the fragment reads per MFMA and the epilogue as they are.
+template <int GATHER, bool PIPE, bool STATS, int ABL = 0, int ILV = 0, int WM = 2>
+__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm16_kernel(const TcGemmParams p, const int order) {
+  constexpr int BM = T16_WT * WM;                          // tile rows: 160 | 320
+  constexpr int RSTEP = 16 * WM;                           // rows per loader pass (threads / 8): 32 | 64
+  constexpr int RA = BM / RSTEP;                           // loader passes over the A rows: 5
+  constexpr int RB = (T16_BN + RSTEP - 1) / RSTEP;         // ... over the W rows: 5 | 3 (the third half empty)
+  constexpr int STAGE = (BM + T16_BN) * TC_BK * 2;         // 40 | 60 KiB
+  constexpr int PIECE = RSTEP * TC_BK * 2;                 // LDS bytes from one loader pass to the next
+  static_assert(WM == 2 || (!STATS && ABL == 0), "statistics and timing builds exist for the 160-row tile only");
+  // WM = 4: the third W pass covers rows 128..191 of a 160-row tile.  Its upper half (waves 4..7) requests nothing real
+  // (offsets out of range -> zeros), but a request it must be -- the counted waits assume the same number per wave -- and
+  // zeros written behind the W rows would land in the next stage's A rows: those four pieces go to a 4 KiB dump
+  constexpr int DUMP = WM == 4 ? 4096 : 0;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE + DUMP];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -64,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(const TcGemmParams p, co
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
   const int tiles_n = (p.n + T16_BN - 1) / T16_BN;
-  const int tiles_m = (p.m + T16_BM - 1) / T16_BM;
+  const int tiles_m = (p.m + BM - 1) / BM;
   int tile_m, tile_n;
   tc_tile_of_block(blockIdx.x, tiles_m, tiles_n, order, tile_m, tile_n);
   if (tile_m >= tiles_m) return;
@@ -76,31 +91,36 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(const TcGemmParams p, co
   // applied to the SOURCE chunk because the LDS destination of a DMA piece is lane-linear
   const int lrow = tid >> 3;
   const int chunk = (tid & 7) ^ ((lrow >> 1) & 7);
-  AGather<GATHER, T16_R> ag;
-  ag.init(p, tile_m * T16_BM, lrow, 32, chunk);
+  AGather<GATHER, RA> ag;
+  ag.init(p, tile_m * BM, lrow, RSTEP, chunk);
   const tc_rsrc_t a_rsrc = tc_a_rsrc(p, bz, ag.row_lo);       // block-relative: 31-bit offsets span one tile's rows
-  uint32_t b_voff[T16_R];
+  uint32_t b_voff[RB];
 #pragma unroll
-  for (int i = 0; i < T16_R; ++i) {
-    const int n = tile_n * T16_BN + lrow + 32 * i;
-    b_voff[i] = n < p.n ? (uint32_t)((int64_t)n * p.ldw * 2 + chunk * 16) : TC_OOB;
+  for (int i = 0; i < RB; ++i) {
+    const int nl = lrow + RSTEP * i;                        // (the tall tile's third pass covers W rows 128..191: 160.. are no rows)
+    const int n = tile_n * T16_BN + nl;
+    b_voff[i] = (nl < T16_BN && n < p.n) ? (uint32_t)((int64_t)n * p.ldw * 2 + chunk * 16) : TC_OOB;
   }
   const bool k_ragged = (p.k & (TC_BK - 1)) != 0;
 
   auto load_tile = [&](int kb, int stage) {
     const int k0 = kb * TC_BK;
-    uint32_t a_voff[T16_R], a_soff;
+    uint32_t a_voff[RA], a_soff;
     ag.offsets(p, k0, chunk, a_voff, a_soff);
     const uint32_t kill = (k_ragged && (k0 + chunk * 8 >= p.k)) ? TC_OOB : 0u;
-    char* sa = smem + stage * T16_STAGE + wave_u * 1024;
-    char* sb = sa + T16_BM * TC_BK * 2;
+    char* sa = smem + stage * STAGE + wave_u * 1024;
+    char* sb = sa + BM * TC_BK * 2;
     if (ABL != 3 && ABL != 4) {
 #pragma unroll
-      for (int i = 0; i < T16_R; ++i) glds16(w_rsrc, sb + i * 4096, b_voff[i] | kill, (uint32_t)k0 * 2u);
+      for (int i = 0; i < RB; ++i) {
+        char* d = sb + i * PIECE;
+        if (WM == 4 && i == RB - 1 && wave_u >= 4) d = smem + 2 * STAGE + (wave_u - 4) * 1024;
+        glds16(w_rsrc, d, b_voff[i] | kill, (uint32_t)k0 * 2u);
+      }
     }
-    if (ABL == 0 || (ABL == 1 && ((k0 / p.cin) % 3) == 0)) {
+    if (ABL == 0 || ABL == 3 || (ABL == 1 && ((k0 / p.cin) % 3) == 0)) {
 #pragma unroll
-      for (int i = 0; i < T16_R; ++i) glds16(a_rsrc, sa + i * 4096, a_voff[i] | kill, a_soff);
+      for (int i = 0; i < RA; ++i) glds16(a_rsrc, sa + i * PIECE, a_voff[i] | kill, a_soff);
     }
   };
 
@@ -124,8 +144,8 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(const TcGemmParams p, co
   const int b_sw = ((wn * T16_WT + frow) >> 1) & 7;
 
   auto compute = [&](int stage) {
-    const char* sa = smem + stage * T16_STAGE;
-    const char* sb = sa + T16_BM * TC_BK * 2;
+    const char* sa = smem + stage * STAGE;
+    const char* sb = sa + BM * TC_BK * 2;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[T16_NT], bf[T16_NT];
@@ -149,52 +169,74 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(const TcGemmParams p, co
     const g8_srd_t w_srd = g8_make_srd(reinterpret_cast<const bf16_t*>(p.w) + bz * p.stride_w, tc_w_extent(p));
     // the slim request state of the persistent kernels (per row a byte offset and a tap mask; stride-1 3x3 only: the
     // host keeps stride 2 / fused upsample on the plain loop) -- AGather's generic path costs 15 more registers
-    G8Gather<GATHER, 32, T16_R> sg;
-    sg.init(p, tile_m * T16_BM, lrow, chunk);
+    G8Gather<GATHER, RSTEP, RA> sg;
+    sg.init(p, tile_m * BM, lrow, chunk);
     const g8_srd_t a_srd = g8_make_srd(reinterpret_cast<const bf16_t*>(p.a) + bz * p.stride_a + sg.row_lo * p.lda,
                                        tc_a_extent(p) - sg.row_lo * p.lda * 2);
     const int tpt = GATHER == TC_GATHER_LINEAR ? 1 : p.cin / TC_BK;     // K-tiles per tap (cin % 64 == 0: host)
     const uint32_t tap_magic = (65536u + tpt - 1) / tpt;                // kb / tpt as a multiply-high, exact for kb < 1024
-    // the ten requests of one K-step: pieces 0..4 = W row passes, 5..9 = A row passes
-    uint32_t r_avoff[T16_R], r_asoff = 0, r_wsoff = 0, r_kill = 0, r_dst = 0;
-    auto prep = [&](int kb, int stage) {
+    // the RB + RA (ten | eight) requests of one K-step: pieces 0..RB-1 = W row passes, then the A row passes
+    uint32_t r_avoff[RA], r_asoff = 0, r_wsoff = 0, r_dst = 0;
+    int r_tap = -1;                                       // the tap r_avoff was formed for: the row offsets change with the TAP
+    auto prep = [&](int kb, int stage) {                  // (every cin / 64 K-steps), only the scalar offset with the K-step
       const int k0 = kb * TC_BK;
       int tap = 0;
-      uint32_t delta = 0;
       r_asoff = (uint32_t)k0 * 2u;
       if (GATHER != TC_GATHER_LINEAR) {
         tap = (int)(((uint32_t)kb * tap_magic) >> 16);
         r_asoff = (uint32_t)(k0 - tap * p.cin) * 2u;
+      }
+      uint32_t kill = 0u;
+      if (k_ragged && kb == nk - 1) {                     // the K tail: its chunks are zero-filled by an out-of-range offset.
+        kill = (k0 + chunk * 8 >= p.k) ? TC_OOB : 0u;     // Only the tile's LAST requests see it, so W's offsets take it for good
+#pragma unroll
+        for (int i = 0; i < RB; ++i) b_voff[i] |= kill;
+        r_tap = -1;
+      }
+      if (tap != r_tap) {
+        r_tap = tap;
+        uint32_t delta = 0;
         if (GATHER == TC_GATHER_CONV3x3) {
           const int ty = (tap * 11) >> 5;                               // tap / 3 for tap < 9
           delta = (uint32_t)(((ty - 1) * p.w_in + (tap - ty * 3 - 1)) * p.lda * 2);
-        } else {
+        } else if (GATHER == TC_GATHER_CONVT3) {
           delta = (uint32_t)((tap - 1) * p.h_out * p.w_out * p.lda * 2);
         }
-      }
 #pragma unroll
-      for (int q = 0; q < T16_R; ++q) r_avoff[q] = sg.voff(q, tap, delta);
-      r_kill = (k_ragged && (k0 + chunk * 8 >= p.k)) ? TC_OOB : 0u;
+        for (int q = 0; q < RA; ++q) r_avoff[q] = sg.voff(q, tap, delta) | kill;
+      }
       r_wsoff = (uint32_t)k0 * 2u;
-      r_dst = lds0 + (uint32_t)(stage * T16_STAGE + wave_u * 1024);
+      r_dst = lds0 + (uint32_t)(stage * STAGE + wave_u * 1024);
     };
-    auto issue = [&](auto Q_) {
+    // piece q of the prepared K-step: (descriptor, LDS destination, row offset, scalar offset)
+    auto q_dst = [&](auto Q_) -> uint32_t {
       constexpr int q = decltype(Q_)::value;
-      if constexpr (q < T16_R) g8_dma16(w_srd, r_dst + T16_BM * TC_BK * 2 + q * 4096, b_voff[q] | r_kill, r_wsoff);
-      else g8_dma16(a_srd, r_dst + (q - T16_R) * 4096, r_avoff[q - T16_R] | r_kill, r_asoff);
+      if constexpr (q < RB) {
+        uint32_t d = r_dst + BM * TC_BK * 2 + q * PIECE;
+        if (WM == 4 && q == RB - 1 && wave_u >= 4) d = lds0 + 2 * STAGE + (wave_u - 4) * 1024;      // (see DUMP)
+        return d;
+      } else {
+        return r_dst + (q - RB) * PIECE;
+      }
+    };
+    auto issue_pair = [&](auto I_) {                    // the two pieces that go behind MFMA row i (the last pair may be short)
+      constexpr int q0 = 2 * decltype(I_)::value, q1 = q0 + 1;
+      if constexpr (q1 < RB) {
+        g8_dma16x2(w_srd, q_dst(ic<q0>{}), b_voff[q0], r_wsoff, w_srd, q_dst(ic<q1>{}), b_voff[q1], r_wsoff);
+      } else if constexpr (q0 < RB) {
+        g8_dma16x2(w_srd, q_dst(ic<q0>{}), b_voff[q0], r_wsoff, a_srd, q_dst(ic<q1>{}), r_avoff[q1 - RB], r_asoff);
+      } else if constexpr (q1 < RB + RA) {
+        g8_dma16x2(a_srd, q_dst(ic<q0>{}), r_avoff[q0 - RB], r_asoff, a_srd, q_dst(ic<q1>{}), r_avoff[q1 - RB], r_asoff);
+      } else if constexpr (q0 < RB + RA) {
+        g8_dma16(a_srd, q_dst(ic<q0>{}), r_avoff[q0 - RB], r_asoff);
+      }
     };
     auto issue_all = [&]() {
-      issue(ic<0>{}); issue(ic<1>{}); issue(ic<2>{}); issue(ic<3>{}); issue(ic<4>{});
-      issue(ic<5>{}); issue(ic<6>{}); issue(ic<7>{}); issue(ic<8>{}); issue(ic<9>{});
-    };
-    auto issue_pair = [&](auto I_) {                    // the two pieces that go behind MFMA row i
-      constexpr int i = decltype(I_)::value;
-      issue(ic<2 * i>{});
-      issue(ic<2 * i + 1>{});
+      issue_pair(ic<0>{}); issue_pair(ic<1>{}); issue_pair(ic<2>{}); issue_pair(ic<3>{}); issue_pair(ic<4>{});
     };
     auto read_frags = [&](int stage, int ks, bf16x8 (&af)[T16_NT], bf16x8 (&bf)[T16_NT]) {
-      const char* sa = smem + stage * T16_STAGE;
-      const char* sb = sa + T16_BM * TC_BK * 2;
+      const char* sa = smem + stage * STAGE;
+      const char* sb = sa + BM * TC_BK * 2;
       const int ca = ((ks * 4 + fq) ^ a_sw) << 4;
       const int cb = ((ks * 4 + fq) ^ b_sw) << 4;
 #pragma unroll
@@ -235,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(const TcGemmParams p, co
       if (nk > 1) {
         prep(1, 1);
         issue_all();
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * T16_R) : "memory");       // step 0 has landed, step 1 may be in flight
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RA + RB) : "memory");         // step 0 has landed, step 1 may be in flight
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
@@ -269,8 +311,8 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(const TcGemmParams p, co
     load_tile(0, 0);
     if (nk > 1) load_tile(1, 1);
     for (int kb = 0; kb < nk; ++kb) {
-      // stage kb & 1 has landed (the 2 * T16_R requests of the other stage may stay in flight), for every wave
-      if (kb + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * T16_R) : "memory");
+      // stage kb & 1 has landed (the RA + RB requests of the other stage may stay in flight), for every wave
+      if (kb + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RA + RB) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       compute(kb & 1);
@@ -312,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(const TcGemmParams p, co
 #pragma unroll
       for (int r = 0; r < 4; ++r) slab[(fq * 4 + r) * T16_WT + j * 16 + frow] = acc[i][j][r];
     // the same wave reads back (LDS operations of one wave complete in order): 160 vectors over 64 lanes
-    const int row_base = tile_m * T16_BM + wm * T16_WT + i * 16;
+    const int row_base = tile_m * BM + wm * T16_WT + i * 16;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       const int v = lane + 64 * q;
@@ -447,10 +489,43 @@ int tc_gemm_tile16_try(const TcGemmParams& p, int batch, hipStream_t s, bool dry
     if (abl == 4) hipLaunchKernelGGL((gemm16_kernel<TC_GATHER_CONV3x3, false, false, 4>), grid, block, 0, s, p, order);
     return 1;
   }
-  // TC_G16_ILV = 0 (default) | 1 | 2: requests between the MFMAs (see the kernel header); read per call (A/B runs)
-  const int ilv = [] { const char* e = getenv("TC_G16_ILV"); return e ? atoi(e) : 0; }();
-  const bool ilv_ok = (p.gather == TC_GATHER_LINEAR || (p.cin % TC_BK) == 0) && p.k < 1024 * TC_BK &&
+  // TC_G16_ILV: requests between the MFMAs (see the kernel header).  Unset = loop 2 for the convolutions, the plain loop
+  // for linear problems (measured, profiles/r04_g16_tall_ilv_bench.txt: 3x3 / temporal convolutions 1.01-1.03x on the
+  // 160-row tile, linear 0.98-1.02x; inside the UNet 8.29 / 8.30 against 8.27 / 8.28 frames/s, alternating on one lease:
+  // profiles/r04_clip_ab_g16.txt); 0 = never; 1 | 2 = that loop wherever it can run.  Read per call (A/B runs).
+  const bool ilv_ok = (p.gather == TC_GATHER_LINEAR || ((p.cin % TC_BK) == 0 && p.cin <= 4096)) && p.k < 1024 * TC_BK &&
                       (p.gather != TC_GATHER_CONV3x3 || (p.stride == 1 && !p.upsample && p.pad == 1));
+  const int ilv = [&] { const char* e = getenv("TC_G16_ILV"); return e ? atoi(e) : (p.gather != TC_GATHER_LINEAR ? 2 : 0); }();
+  // TC_G16_TALL: the 320 x 160 tile on eight waves (WM = 4), one block per CU.  0 (default) = never; 1 = convolutions whose
+  // tall tiles fill whole rounds of the 256 CUs as well as the 160-row tiles fill their 512 slots (levels 0 / 1 of the
+  // UNet); 2 = whenever the shape allows.  OFF although it wins kernel by kernel (with loop 2: level 0 1.035-1.06x, level
+  // 1 1.09x; level 2 has 128 tall tiles: 0.8x; linear problems 0.94-1.05x): inside the UNet, alternating on one lease, it
+  // LOSES 0.8 % of a clip (8.22 vs 8.27-8.29 frames/s, and 7.32 vs 7.38 together with loop 2:
+  // profiles/r04_clip_ab_g16.txt) -- one 8-wave block per CU has nothing to fill its ramp and tail with.
+  const int tall = [] { const char* e = getenv("TC_G16_TALL"); return e ? atoi(e) : 0; }();
+  if (tall >= 1 && !stats && (ilv == 0 || ilv_ok) && (tall == 2 || p.gather != TC_GATHER_LINEAR)) {
+    const int tm4 = (p.m + 2 * T16_BM - 1) / (2 * T16_BM);
+    const int64_t t4 = (int64_t)tiles_n * tm4 * batch;
+    const double e4 = (double)t4 / (double)((t4 + 255) / 256 * 256) * ((double)p.m / ((double)tm4 * 2 * T16_BM));
+    const double e2 = (double)tiles / (double)((tiles + 511) / 512 * 512) * ((double)p.m / ((double)tiles_m * T16_BM));
+    if (tall == 2 || (t4 >= 256 && e4 >= e2 - 0.02)) {
+      const int64_t nb4 = (int64_t)tiles_n * 8 * ((tm4 + 7) / 8);
+      dim3 grid4((unsigned)nb4, 1, (unsigned)batch), block4(512);
+#define TC_LAUNCH16_TALL(G)                                                                                          \
+  do {                                                                                                               \
+    if (ilv == 1) hipLaunchKernelGGL((gemm16_kernel<G, false, false, 0, 1, 4>), grid4, block4, 0, s, p, order);      \
+    else if (ilv == 2) hipLaunchKernelGGL((gemm16_kernel<G, false, false, 0, 2, 4>), grid4, block4, 0, s, p, order); \
+    else hipLaunchKernelGGL((gemm16_kernel<G, false, false, 0, 0, 4>), grid4, block4, 0, s, p, order);               \
+  } while (0)
+      switch (p.gather) {
+        case TC_GATHER_LINEAR: TC_LAUNCH16_TALL(TC_GATHER_LINEAR); break;
+        case TC_GATHER_CONV3x3: TC_LAUNCH16_TALL(TC_GATHER_CONV3x3); break;
+        default: TC_LAUNCH16_TALL(TC_GATHER_CONVT3); break;
+      }
+#undef TC_LAUNCH16_TALL
+      return 1;
+    }
+  }
   if ((ilv == 1 || ilv == 2) && !stats && ilv_ok) {
 #define TC_LAUNCH16_ILV(G)                                                                                       \
   do {                                                                                                           \

@@ -157,6 +157,13 @@ struct AGather {
   uint32_t vbits[R];   // convolution: bit t set if tap t of this row is inside the image
   int f[R], y[R], x[R];  // generic 3x3 path (stride 2 / fused upsample) only
   bool ok[R];
+  // The row offsets of a convolution change with the TAP, i.e. every cin / 64 K-steps; between taps only the scalar offset
+  // moves.  offsets() therefore keeps the offsets of the tap it last formed them for (5 masked adds per row and K-step,
+  // and the K-step -> tap division, were 45 of the ~115 vector and most of the ~110 scalar instructions a wave spent per
+  // K-step beside its 50 MFMAs: profiles/r04_pmc_g16.txt) and finds the tap by a multiply-high where that is exact.
+  uint32_t cvoff[R];
+  int ctap;              // the tap cvoff belongs to; -1: none yet
+  uint32_t tap_magic;    // ceil(65536 / (cin / 64)): K-tile -> tap, exact for K-tiles < 1024 and cin <= 4096; 0: divide
 
   __device__ __forceinline__ bool fast3x3(const TcGemmParams& p) const {
     return p.stride == 1 && !p.upsample && p.pad == 1;
@@ -165,6 +172,12 @@ struct AGather {
   __device__ __forceinline__ void init(const TcGemmParams& p, int tile_row0, int lrow, int row_step, int chunk) {
     const int hw = p.h_out * p.w_out;
     row_lo = tc_tile_row_lo<GATHER>(p, tile_row0);
+    ctap = -1;
+    tap_magic = 0;
+    if (GATHER != TC_GATHER_LINEAR && (p.cin % TC_BK) == 0 && p.cin <= 4096 && p.k < 1024 * TC_BK) {
+      const uint32_t tpt = (uint32_t)(p.cin / TC_BK);
+      tap_magic = (65536u + tpt - 1) / tpt;
+    }
 #pragma unroll
     for (int i = 0; i < R; ++i) {
       const int mm = tile_row0 + lrow + row_step * i;
@@ -196,41 +209,45 @@ struct AGather {
     }
   }
 
-  // voffset of every row and the scalar soffset for the K-block starting at k0
-  __device__ __forceinline__ void offsets(const TcGemmParams& p, int k0, int chunk, uint32_t (&voff)[R],
-                                          uint32_t& soff) const {
+  // voffset of every row and the scalar soffset for the K-block starting at k0 (a multiple of TC_BK)
+  __device__ __forceinline__ void offsets(const TcGemmParams& p, int k0, int chunk, uint32_t (&voff)[R], uint32_t& soff) {
     if (GATHER == TC_GATHER_LINEAR) {
       soff = (uint32_t)k0 * 2u;
 #pragma unroll
       for (int i = 0; i < R; ++i) voff[i] = base[i];
-    } else if (GATHER == TC_GATHER_CONV3x3) {
-      const int tap = k0 / p.cin;
-      soff = (uint32_t)(k0 - tap * p.cin) * 2u;
-      const int dy = tap / 3 - p.pad, dx = tap - (tap / 3) * 3 - p.pad;
-      if (fast3x3(p)) {
-        const uint32_t delta = (uint32_t)((dy * p.w_in + dx) * p.lda * 2);
-#pragma unroll
-        for (int i = 0; i < R; ++i) voff[i] = ((vbits[i] >> tap) & 1u) ? base[i] + delta : TC_OOB;
-      } else {
-        const int hv = p.upsample ? p.h_in * 2 : p.h_in;
-        const int wv = p.upsample ? p.w_in * 2 : p.w_in;
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-          int iy = y[i] * p.stride + dy;
-          int ix = x[i] * p.stride + dx;
-          const bool v = ok[i] && iy >= 0 && iy < hv && ix >= 0 && ix < wv;
-          if (p.upsample) { iy >>= 1; ix >>= 1; }
-          const int64_t src = ((int64_t)f[i] * p.h_in + iy) * p.w_in + ix;
-          voff[i] = v ? (uint32_t)((src - row_lo) * p.lda * 2 + chunk * 16) : TC_OOB;
-        }
-      }
-    } else {  // CONVT3
-      const int tap = k0 / p.cin;
-      soff = (uint32_t)(k0 - tap * p.cin) * 2u;
-      const uint32_t delta = (uint32_t)((tap - 1) * p.h_out * p.w_out * p.lda * 2);
-#pragma unroll
-      for (int i = 0; i < R; ++i) voff[i] = ((vbits[i] >> tap) & 1u) ? base[i] + delta : TC_OOB;
+      return;
     }
+    const int tap = tap_magic ? (int)((((uint32_t)k0 / TC_BK) * tap_magic) >> 16) : k0 / p.cin;
+    soff = (uint32_t)(k0 - tap * p.cin) * 2u;
+    if (tap != ctap) {                                   // block-uniform
+      ctap = tap;
+      if (GATHER == TC_GATHER_CONV3x3) {
+        const int dy = tap / 3 - p.pad, dx = tap - (tap / 3) * 3 - p.pad;
+        if (fast3x3(p)) {
+          const uint32_t delta = (uint32_t)((dy * p.w_in + dx) * p.lda * 2);
+#pragma unroll
+          for (int i = 0; i < R; ++i) cvoff[i] = ((vbits[i] >> tap) & 1u) ? base[i] + delta : TC_OOB;
+        } else {
+          const int hv = p.upsample ? p.h_in * 2 : p.h_in;
+          const int wv = p.upsample ? p.w_in * 2 : p.w_in;
+#pragma unroll
+          for (int i = 0; i < R; ++i) {
+            int iy = y[i] * p.stride + dy;
+            int ix = x[i] * p.stride + dx;
+            const bool v = ok[i] && iy >= 0 && iy < hv && ix >= 0 && ix < wv;
+            if (p.upsample) { iy >>= 1; ix >>= 1; }
+            const int64_t src = ((int64_t)f[i] * p.h_in + iy) * p.w_in + ix;
+            cvoff[i] = v ? (uint32_t)((src - row_lo) * p.lda * 2 + chunk * 16) : TC_OOB;
+          }
+        }
+      } else {  // CONVT3
+        const uint32_t delta = (uint32_t)((tap - 1) * p.h_out * p.w_out * p.lda * 2);
+#pragma unroll
+        for (int i = 0; i < R; ++i) cvoff[i] = ((vbits[i] >> tap) & 1u) ? base[i] + delta : TC_OOB;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) voff[i] = cvoff[i];
   }
 };
 

@@ -113,6 +113,26 @@ __device__ __forceinline__ void g8_dma16(g8_srd_t srd, uint32_t lds_dst, uint32_
       : "memory");
 }
 
+// Two requests in one statement: one hazard pad and one save / restore of M0 for the pair (9 instructions instead of 12;
+// gemm16's interleaved loops issue their ten pieces as five pairs).
+__device__ __forceinline__ void g8_dma16x2(g8_srd_t srd0, uint32_t dst0, uint32_t voff0, uint32_t soff0,
+                                           g8_srd_t srd1, uint32_t dst1, uint32_t voff1, uint32_t soff1) {
+  uint32_t keep;
+  asm volatile(
+      "s_nop 4\n\t"
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+      "s_mov_b32 m0, %5\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %6, %7, %8 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(dst0), "v"(voff0), "s"(srd0), "s"(soff0), "s"(dst1), "v"(voff1), "s"(srd1), "s"(soff1)
+      : "memory");
+}
+
 __device__ __forceinline__ void g8_barrier() {
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
