@@ -43,7 +43,14 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
   return v;
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// SiLU on the hardware's reciprocal and base-2 exponential (v_rcp_f32 / v_exp_f32, 1 ulp each: |error| <= 3e-7 relative,
+// four orders of magnitude below a bf16 ulp): `x / (1 + __expf(-x))` compiles to the correctly rounded division -- two
+// v_div_scale, v_rcp, six fused multiply-adds, v_div_fmas, v_div_fixup -- and a range-checked exponential, 17 vector
+// instructions per element of every GroupNorm + SiLU pass (64 x {2 div_scale, div_fmas, div_fixup} in gn_apply's ISA);
+// this form is 5.  Limits as before: x -> -inf gives -0 (exp2 = +inf, rcp = 0), +inf stays +inf, NaN stays NaN.
+__device__ __forceinline__ float silu_f(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
+}
 // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below a bf16 ulp): branch-free and an
 // order of magnitude less code than libdevice's erff, which matters in the unrolled GEMM epilogue.
 // The reciprocal is the hardware's v_rcp_f32 (1 ulp): the correctly rounded one is an eleven-instruction

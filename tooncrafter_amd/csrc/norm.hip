@@ -191,10 +191,12 @@ __global__ __launch_bounds__(256) void gn_finalize_part_kernel(const float* __re
   }
 }
 
+// SILU is a template parameter: as a run-time flag every element paid for the activation AND a select
+template <bool SILU>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               const float* __restrict__ stats, int rows, int c,
-                                                              int chunk_rows, int silu) {
+                                                              int chunk_rows) {
   const GnGeo g = gn_geo(c);
   const int tid = threadIdx.x;
   int rlane, vec[GN_MAX_SLOTS];
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __re
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               const float v = f[e] * sc[s][e] + sh[s][e];
-              f[e] = silu ? silu_f(v) : v;
+              f[e] = SILU ? silu_f(v) : v;
             }
             *reinterpret_cast<u32x4*>(ys + (int64_t)rr * c + vec[s] * 8) = pack8(f);
           }
@@ -263,10 +265,10 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __re
 // vector instead of 4: the 26-vector instance would spill): after this the packed words are "new" values
 __device__ __forceinline__ void gn_opaque(u32x4& v) { asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])); }
 
-template <int T, int NV>
+template <int T, int NV, bool SILU>
 __global__ __launch_bounds__(T) void gn_onepass_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       int rows, int c, int vu, float eps, int silu) {
+                                                       int rows, int c, int vu, float eps) {
   constexpr int NW = T / 64;
   __shared__ float red[2][NW][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(T) void gn_onepass_kernel(const bf16_t* __restrict_
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float t = f[e] * sc[e] + sh[e];
-          f[e] = silu ? silu_f(t) : t;
+          f[e] = SILU ? silu_f(t) : t;
         }
         *reinterpret_cast<u32x4*>(ys + (int64_t)r * c) = pack8(f);
       }
@@ -561,8 +563,13 @@ extern "C" int tc_groupnorm(const tc_bf16* x, tc_bf16* y, const float* gamma, co
       const int64_t bytes = nvec * 16 * samples * (c / u);
       bool done = nblk >= 128 || bytes <= (4 << 20);
       if (!done) {}
-      else if (fits(256, 4)) hipLaunchKernelGGL((gn_onepass_kernel<256, 4>), grid, dim3(256), 0, s, xb, yb, gamma, beta, rows, c, vu, eps, silu);
-      else if (fits(256, 13)) hipLaunchKernelGGL((gn_onepass_kernel<256, 13>), grid, dim3(256), 0, s, xb, yb, gamma, beta, rows, c, vu, eps, silu);
+      else if (fits(256, 4)) {
+        if (silu) hipLaunchKernelGGL((gn_onepass_kernel<256, 4, true>), grid, dim3(256), 0, s, xb, yb, gamma, beta, rows, c, vu, eps);
+        else hipLaunchKernelGGL((gn_onepass_kernel<256, 4, false>), grid, dim3(256), 0, s, xb, yb, gamma, beta, rows, c, vu, eps);
+      } else if (fits(256, 13)) {
+        if (silu) hipLaunchKernelGGL((gn_onepass_kernel<256, 13, true>), grid, dim3(256), 0, s, xb, yb, gamma, beta, rows, c, vu, eps);
+        else hipLaunchKernelGGL((gn_onepass_kernel<256, 13, false>), grid, dim3(256), 0, s, xb, yb, gamma, beta, rows, c, vu, eps);
+      }
       else done = false;
       if (done) {
         TC_LAUNCH_CHECK();
@@ -580,8 +587,10 @@ extern "C" int tc_groupnorm(const tc_bf16* x, tc_bf16* y, const float* gamma, co
   hipLaunchKernelGGL(gn_finalize_kernel, dim3((samples * 32 + 3) / 4), block, 0, s, part, stats, samples, rows, c, nch,
                      eps);
   TC_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, s, reinterpret_cast<const bf16_t*>(x),
-                     reinterpret_cast<bf16_t*>(y), gamma, beta, stats, rows, c, cr, silu);
+  if (silu) hipLaunchKernelGGL(gn_apply_kernel<true>, grid, block, 0, s, reinterpret_cast<const bf16_t*>(x),
+                               reinterpret_cast<bf16_t*>(y), gamma, beta, stats, rows, c, cr);
+  else hipLaunchKernelGGL(gn_apply_kernel<false>, grid, block, 0, s, reinterpret_cast<const bf16_t*>(x),
+                          reinterpret_cast<bf16_t*>(y), gamma, beta, stats, rows, c, cr);
   TC_LAUNCH_CHECK();
   return TC_OK;
 }
@@ -601,8 +610,10 @@ extern "C" int tc_groupnorm_part(const tc_bf16* x, tc_bf16* y, const float* gamm
   hipLaunchKernelGGL(gn_finalize_part_kernel, dim3(samples * 32), dim3(256), 0, s, part, stats, samples, rows, c,
                      part_rows, eps);
   TC_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(nch, samples), dim3(GN_THREADS), 0, s, reinterpret_cast<const bf16_t*>(x),
-                     reinterpret_cast<bf16_t*>(y), gamma, beta, stats, rows, c, cr, silu);
+  if (silu) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(nch, samples), dim3(GN_THREADS), 0, s, reinterpret_cast<const bf16_t*>(x),
+                               reinterpret_cast<bf16_t*>(y), gamma, beta, stats, rows, c, cr);
+  else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(nch, samples), dim3(GN_THREADS), 0, s, reinterpret_cast<const bf16_t*>(x),
+                          reinterpret_cast<bf16_t*>(y), gamma, beta, stats, rows, c, cr);
   TC_LAUNCH_CHECK();
   return TC_OK;
 }
