@@ -1,0 +1,321 @@
+// Tap-reuse convolutions on 160x160 tiles, gfx950: the 3x3 (stride 1, pad 1) and the temporal (3,1,1) convolutions of the
+// UNet with the A operand of ALL taps read from ONE halo patch in LDS.  OPT-IN (TC_CONV_HALO=1|2, default off): written in a
+// session without GPU access, cross-compiled and index-checked on the CPU (tests/test_conv_halo_cpu.py mirrors every
+// address formula below in numpy), NOT yet run on an MI355X -- tests/test_gpu_conv_halo.py is the first thing to run.
+//
+// Why.  The implicit-GEMM kernels (gemm16.hip) request the A tile once per K-step = once per (tap, 64 channels): every
+// input pixel goes L2 -> LDS nine times per output-column tile (three times for the temporal taps).  The timing builds
+// of round 4 (profiles/r04_g16_ablate.txt) say what that costs on the level-0 3x3 convolution: 145 us with all
+// requests, 104 without A's, 91 without any -- and the chip's L2->LDS path delivers 12.6-18 TB/s inside a GEMM against
+// the 31 TB/s a 160x160x64 step needs at the MFMA roof.  Here a block owns a 2-D PATCH of the output:
+//   3x3     : 10 image rows x 16 pixels of one frame        -> halo 12 x 18 = 216 pixels
+//   temporal: 10 consecutive pixels x the clip's 16 frames  -> halo 10 x 18 = 180 (frames -1 and 16 are the zero padding)
+// = 160 GEMM rows either way, tile row = 16 y + x, so one 16-row MFMA block is one image row (one pixel's frames).  Per
+// 64-channel chunk the halo patch is brought in ONCE (216 x 128 B instead of 9 x 160 x 128 B: 6.7x fewer A bytes; 2.7x
+// for the temporal taps) and the K loop runs chunk-major: for each chunk, for each tap, 50 MFMAs per wave against the
+// W tile of (tap, chunk) -- the same packed weights, visited in another order (k0 = tap * cin + 64 chunk).
+//   * A fragments of tap (ty, tx): halo pixel hp = (y + ty) * 18 + (x + tx), i.e. the 16 lanes of an MFMA row block read
+//     16 CONSECUTIVE halo pixels from an arbitrary base.  The 16-byte segment index is XOR-swizzled by (hp & 7): every
+//     ds_read_b128 lane group then touches 16 distinct bank slots for every base (gemm16's (row >> 1) & 7 is conflict-free
+//     for 16-aligned bases only; both checked by brute force in the CPU test).
+//   * The halo goes through REGISTERS (7 buffer_load_dwordx4 per thread and chunk, requested at the start of the chunk's
+//     last tap, written with ds_write_b128 behind that step's barrier): a DMA fill would have to wait until the last
+//     fragment of the old chunk is read and would expose its whole latency once per chunk; a second halo buffer would
+//     cost the second resident block (LDS: 28 KiB halo + 2 x 20 KiB W stages = 68 KiB, two blocks per CU).
+//   * W tiles: LDS-DMA from inline asm into two stages, one K-step ahead (gemm_persist.h g8_dma16), vmcnt(0) + barrier
+//     per step -- the plain loop; the interleaved loops of gemm16 can follow once this one is measured.
+//   * Epilogue: gemm16's (per-wave fp32 slab, 16-byte row vectors, bias / row bias / activation / residual), with the
+//     tile row -> output row map of the patch.
+// Summation order over K differs from the implicit GEMM's (chunk-major instead of tap-major): results agree to fp32
+// rounding of the accumulators, not bit for bit.
+#include "gemm_persist.h"
+
+#include <stdlib.h>
+
+namespace {
+
+constexpr int CH_BN = 160, CH_WT = 80, CH_NT = 5;
+constexpr int CH_HX = 18;                                  // halo patch width (16 + 2) for both geometries
+constexpr int CH_A_BYTES = 28 * 1024;                      // 216 (180) halo pixels x 128 B, padded to whole KiB
+constexpr int CH_W_STAGE = CH_BN * TC_BK * 2;              // 20 KiB
+constexpr int CH_NV = 7;                                   // halo vectors per thread and chunk: ceil(216 * 8 / 256)
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <int GATHER>
+struct ChGeo {                                             // 3x3: y = image row, x = pixel; temporal: y = pixel, x = frame
+  static constexpr int TAPS = GATHER == TC_GATHER_CONV3x3 ? 9 : 3;
+  static constexpr int HY = GATHER == TC_GATHER_CONV3x3 ? 12 : 10;
+  static constexpr int NPIX = HY * CH_HX;                  // 216 | 180
+};
+
+template <int GATHER>
+__global__ __launch_bounds__(256, 2) void conv_halo_kernel(const TcGemmParams p, const int order) {
+  using G = ChGeo<GATHER>;
+  __shared__ __attribute__((aligned(1024))) char smem[CH_A_BYTES + 2 * CH_W_STAGE];
+  char* const sA = smem;
+  char* const sW = smem + CH_A_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+  // ---- block -> patch
+  const int hw = p.h_out * p.w_out;
+  const int tiles_n = p.n / CH_BN;
+  int per_img, tiles_m;                                    // patches per frame (3x3) | per clip (temporal)
+  if (GATHER == TC_GATHER_CONV3x3) { per_img = (p.h_out / 10) * (p.w_out / 16); tiles_m = p.frames * per_img; }
+  else { per_img = hw / 10; tiles_m = (p.frames / 16) * per_img; }
+  int tile_m, tile_n;
+  tc_tile_of_block(blockIdx.x, tiles_m, tiles_n, order, tile_m, tile_n);
+  if (tile_m >= tiles_m) return;
+  const int img = tile_m / per_img, pin = tile_m - img * per_img;
+  // output row of patch position (y, x): m = m00 + y * ys + x * xs
+  int64_t m00;
+  int ys, xs, Y0 = 0, X0 = 0;
+  if (GATHER == TC_GATHER_CONV3x3) {
+    const int tpx = p.w_out / 16;
+    const int ty0 = pin / tpx;
+    Y0 = ty0 * 10;
+    X0 = (pin - ty0 * tpx) * 16;
+    m00 = ((int64_t)img * p.h_out + Y0) * p.w_out + X0;
+    ys = p.w_out;
+    xs = 1;
+  } else {
+    m00 = (int64_t)img * 16 * hw + pin * 10;
+    ys = 1;
+    xs = hw;
+  }
+  // lowest source row the patch can touch: the SRD of A starts there (31-bit offsets span one patch)
+  int64_t row_lo = GATHER == TC_GATHER_CONV3x3 ? m00 - p.w_out - 1 : m00;
+  if (row_lo < 0) row_lo = 0;
+
+  const int64_t bz = blockIdx.z;
+  const tc_rsrc_t a_rsrc = tc_a_rsrc(p, bz, row_lo);
+  const g8_srd_t w_srd = g8_make_srd(reinterpret_cast<const bf16_t*>(p.w) + bz * p.stride_w, tc_w_extent(p));
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+  // ---- halo vectors of this thread: v = tid + 256 i -> halo pixel v >> 3, 16-byte segment v & 7 (8 lanes = one pixel's
+  // 128 bytes: coalesced source lines, conflict-free ds_write_b128 groups)
+  uint32_t hv_off[CH_NV];
+  int hv_lds[CH_NV];                                       // -1: no such pixel
+#pragma unroll
+  for (int i = 0; i < CH_NV; ++i) {
+    const int v = tid + 256 * i;
+    const int pix = v >> 3, seg = v & 7;
+    const int hy = pix / CH_HX, hx = pix - hy * CH_HX;
+    bool ok = pix < G::NPIX;
+    int64_t src;
+    if (GATHER == TC_GATHER_CONV3x3) {
+      const int iy = Y0 + hy - 1, ix = X0 + hx - 1;
+      ok = ok && iy >= 0 && iy < p.h_in && ix >= 0 && ix < p.w_in;
+      src = ((int64_t)img * p.h_in + iy) * p.w_in + ix;
+    } else {
+      ok = ok && hx >= 1 && hx <= 16;
+      src = ((int64_t)img * 16 + (hx - 1)) * hw + pin * 10 + hy;
+    }
+    hv_off[i] = ok ? (uint32_t)((src - row_lo) * p.lda * 2 + seg * 16) : TC_OOB;       // outside the image: zeros
+    hv_lds[i] = pix < G::NPIX ? pix * 128 + ((seg ^ (pix & 7)) << 4) : -1;
+  }
+  u32x4 hv[CH_NV];
+  auto load_halo = [&](int chunk_idx) {
+    const uint32_t soff = (uint32_t)chunk_idx * (TC_BK * 2);
+#pragma unroll
+    for (int i = 0; i < CH_NV; ++i) hv[i] = buf_load16(a_rsrc, hv_off[i], soff);
+  };
+  auto store_halo = [&]() {
+#pragma unroll
+    for (int i = 0; i < CH_NV; ++i)
+      if (hv_lds[i] >= 0) *reinterpret_cast<u32x4*>(sA + hv_lds[i]) = hv[i];
+  };
+
+  // ---- W tile requests: thread -> (row lrow + 32 i, 16-byte chunk), the swizzle on the SOURCE chunk (gemm16.hip)
+  const int lrow = tid >> 3;
+  const int wchunk = (tid & 7) ^ ((lrow >> 1) & 7);
+  uint32_t b_voff[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int n = tile_n * CH_BN + lrow + 32 * i;
+    b_voff[i] = n < p.n ? (uint32_t)((int64_t)n * p.ldw * 2 + wchunk * 16) : TC_OOB;
+  }
+  auto request_w = [&](int k0, int stage) {
+    const uint32_t dst = lds0 + (uint32_t)(CH_A_BYTES + stage * CH_W_STAGE + wave_u * 1024);
+    const uint32_t soff = (uint32_t)k0 * 2u;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) g8_dma16(w_srd, dst + i * 4096, b_voff[i], soff);
+  };
+
+  f32x4_t acc[CH_NT][CH_NT];
+#pragma unroll
+  for (int i = 0; i < CH_NT; ++i)
+#pragma unroll
+    for (int j = 0; j < CH_NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // v_mfma_f32_16x16x32_bf16 operands: lane holds row (lane & 15) of a 16-row block, k = 8 (lane >> 4) .. +7 of the slice
+  const int frow = lane & 15;
+  const int fq = lane >> 4;
+  int hp0[CH_NT], b_off[CH_NT];
+#pragma unroll
+  for (int i = 0; i < CH_NT; ++i) {
+    hp0[i] = (wm * 5 + i) * CH_HX + frow;                  // halo pixel of (y = 5 wm + i, x = frow) for tap (0, 0)
+    b_off[i] = (wn * CH_WT + i * 16 + frow) * (TC_BK * 2);
+  }
+  const int b_sw = ((wn * CH_WT + frow) >> 1) & 7;
+
+  auto compute = [&](int stage, int shift) {
+    const char* sb = sW + stage * CH_W_STAGE;
+    int a_addr[CH_NT];
+#pragma unroll
+    for (int i = 0; i < CH_NT; ++i) {
+      const int hp = hp0[i] + shift;
+      a_addr[i] = (hp << 7) + ((fq ^ (hp & 7)) << 4);      // K-slice 0: segment fq; slice 1: segment 4 + fq = this ^ 64
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[CH_NT], bf[CH_NT];
+      const int cb = ((ks * 4 + fq) ^ b_sw) << 4;
+#pragma unroll
+      for (int i = 0; i < CH_NT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sA + (a_addr[i] ^ (ks << 6)));
+#pragma unroll
+      for (int j = 0; j < CH_NT; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(sb + b_off[j] + cb);
+#pragma unroll
+      for (int i = 0; i < CH_NT; ++i)
+#pragma unroll
+        for (int j = 0; j < CH_NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // ---- K loop, chunk-major: step kb = (chunk c, tap t); W(kb + 1) is requested while step kb computes
+  const int nch = p.cin / TC_BK;
+  const int nk = G::TAPS * nch;
+  request_w(0, 0);
+  load_halo(0);
+  store_halo();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int c = 0, tap = 0, ty = 0, tx = 0;                      // tap = 3 ty + tx (3x3) | tx (temporal)
+  for (int kb = 0; kb < nk; ++kb) {
+    const int st = kb & 1;
+    int ntap = tap + 1, nc = c, nty = ty, ntx = tx + 1;
+    if (ntx == 3) { ntx = 0; nty = ty + 1; }
+    if (ntap == G::TAPS) { ntap = 0; nc = c + 1; nty = 0; ntx = 0; }
+    const bool more = kb + 1 < nk;
+    const bool refill = more && ntap == 0;                 // block-uniform: the next step opens a new channel chunk
+    if (more) request_w(ntap * p.cin + nc * TC_BK, st ^ 1);
+    if (refill) load_halo(nc);
+    compute(st, GATHER == TC_GATHER_CONV3x3 ? ty * CH_HX + tx : tx);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // own pieces of W(kb + 1) (and the halo vectors) have landed
+    __syncthreads();                                       // every wave's fragment reads of this step are done
+    if (refill) {
+      store_halo();
+      __syncthreads();
+    }
+    tap = ntap; c = nc; ty = nty; tx = ntx;
+  }
+
+  // ---- epilogue: per wave, five passes of one 16-row MFMA block through a private fp32 slab [16][80] (gemm16.hip),
+  // tile row 16 y + x -> output row m00 + y ys + x xs
+  float* slab = reinterpret_cast<float*>(smem) + wave * (16 * CH_WT);
+  const bf16_t* res_base = p.residual ? reinterpret_cast<const bf16_t*>(p.residual) + bz * p.stride_c : nullptr;
+  char* c_base = reinterpret_cast<char*>(p.c) + bz * p.stride_c * (p.out_f32 ? 4 : 2);
+  const int col_w0 = tile_n * CH_BN + wn * CH_WT;
+  constexpr int VPR = CH_WT / 8;                           // 10 vectors of 8 columns per slab row
+  auto epi_pass = [&](auto I_) {
+    constexpr int i = decltype(I_)::value;
+    // C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg
+#pragma unroll
+    for (int j = 0; j < CH_NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slab[(fq * 4 + r) * CH_WT + j * 16 + frow] = acc[i][j][r];
+    // the same wave reads back (LDS operations of one wave complete in order): 160 vectors over 64 lanes
+    const int64_t row_base = m00 + (int64_t)(wm * 5 + i) * ys;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int v = lane + 64 * q;
+      const int lr = v / VPR, vc = v - lr * VPR;
+      const int m = (int)(row_base + (int64_t)lr * xs);
+      const int n0 = col_w0 + vc * 8;
+      if (v < 16 * VPR && m < p.m && n0 < p.n) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(slab + lr * CH_WT + vc * 8);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(slab + lr * CH_WT + vc * 8 + 4);
+        float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n0);
+          const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n0 + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
+        }
+        if (p.row_bias) {
+          const float* rp = p.row_bias + (int64_t)(m / p.row_div) * p.ldrb + n0;
+          const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp);
+          const f32x4 r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { bv[e] += r0[e]; bv[4 + e] += r1[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = apply_act(x[e] * p.alpha + bv[e], p.act) * p.out_scale;
+        if (res_base) {
+          float rf[8];
+          unpack8(*reinterpret_cast<const u32x4*>(res_base + (int64_t)m * p.ldr + n0), rf);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] += rf[e];
+        }
+        if (p.out_f32) {
+          float* op = reinterpret_cast<float*>(c_base) + (int64_t)m * p.ldc + n0;
+          *reinterpret_cast<f32x4*>(op) = f32x4{x[0], x[1], x[2], x[3]};
+          *reinterpret_cast<f32x4*>(op + 4) = f32x4{x[4], x[5], x[6], x[7]};
+        } else {
+          *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(c_base) + (int64_t)m * p.ldc + n0) = pack8(x);
+        }
+      }
+    }
+  };
+  epi_pass(ic<0>{});
+  epi_pass(ic<1>{});
+  epi_pass(ic<2>{});
+  epi_pass(ic<3>{});
+  epi_pass(ic<4>{});
+}
+
+int conv_halo_mode() {        // TC_CONV_HALO = 0 / unset never | 1 | 2 whenever the shape allows; read per call (A/B runs)
+  const char* e = getenv("TC_CONV_HALO");
+  return e ? atoi(e) : 0;
+}
+
+}  // namespace
+
+// Decide whether the tap-reuse kernel takes this (already validated) convolution, and launch it.  1 = launched, 0 = not
+// taken, -1 = TC_CONV_HALO=2 ("strict", the parity tests) and a convolution was NOT taken: the caller fails the call, so a
+// test that passes under mode 2 has provably run this kernel and not a fallback.
+int tc_conv_halo_try(const TcGemmParams& p, int batch, hipStream_t s, bool dry) {
+  const int mode = conv_halo_mode();
+  if (mode == 0) return 0;
+  if (p.gather != TC_GATHER_CONV3x3 && p.gather != TC_GATHER_CONVT3) return 0;
+  const int declined = mode == 2 ? -1 : 0;
+  if (p.act == TC_ACT_GEGLU || p.gn_part || p.a_norm || (p.n % CH_BN) != 0 || (p.cin % TC_BK) != 0 ||
+      p.k != (p.gather == TC_GATHER_CONV3x3 ? 9 : 3) * p.cin) return declined;
+  int64_t tiles_m;
+  if (p.gather == TC_GATHER_CONV3x3) {
+    if (p.stride != 1 || p.upsample || p.pad != 1 || p.h_in != p.h_out || p.w_in != p.w_out) return declined;
+    if ((p.h_out % 10) != 0 || (p.w_out % 16) != 0) return declined;
+    tiles_m = (int64_t)p.frames * (p.h_out / 10) * (p.w_out / 16);
+  } else {
+    const int hw = p.h_out * p.w_out;
+    if (p.t_len != 16 || (p.frames % 16) != 0 || (hw % 10) != 0) return declined;
+    tiles_m = (int64_t)(p.frames / 16) * (hw / 10);
+    if ((int64_t)17 * hw * p.lda * 2 >= 0x7fffff00LL) return declined;    // a patch spans the clip's 16 frames: 31-bit offsets
+  }
+  if (tiles_m * 160 != p.m) return declined;
+  const int tiles_n = p.n / CH_BN;
+  const int64_t nblk = (int64_t)tiles_n * 8 * ((tiles_m + 7) / 8);
+  if (nblk > 0x7fffffffLL || batch > 65535) return declined;
+  if (dry) return 1;
+  dim3 grid((unsigned)nblk, 1, (unsigned)batch), block(256);
+  const int order = tc_gemm_tile_order(p, tiles_n);
+  if (p.gather == TC_GATHER_CONV3x3) hipLaunchKernelGGL((conv_halo_kernel<TC_GATHER_CONV3x3>), grid, block, 0, s, p, order);
+  else hipLaunchKernelGGL((conv_halo_kernel<TC_GATHER_CONVT3>), grid, block, 0, s, p, order);
+  return 1;
+}

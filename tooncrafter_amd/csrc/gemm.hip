@@ -407,6 +407,7 @@ extern "C" int tc_gemm_gn_rows(const TcGemmParams* pp) {
   if (getenv("TC_GEMM_TILE") && getenv("TC_GEMM_TILE")[0]) return 0;          // forced tile families: tuning runs only
   if (const char* e = getenv("TC_GN_PART")) { if (e[0] == '0') return 0; }    // A/B switch: never emit
   if (tc_gemm_ws_try(p, batch, nullptr, true)) return 0;
+  if (tc_conv_halo_try(p, batch, nullptr, true) != 0) return 0;
   if (tc_gemm8_try(p, batch, nullptr, true)) return 0;
   if (tc_gemm_tile16_try(p, batch, nullptr, true)) return 160;
   if (tc_gemm_wide_try(p, batch, nullptr, false, true)) return 0;
@@ -477,6 +478,14 @@ extern "C" int tc_gemm_bf16(const TcGemmParams* pp, void* stream) {
     return TC_OK;
   }
   if (p.a_norm) return TC_ESHAPE;                                      // only the weight-stationary kernel normalises A rows
+  if (force == 0 && !p.gn_part) {                                      // TC_CONV_HALO only (off by default): tap-reuse patches
+    const int r = tc_conv_halo_try(p, batch, s);
+    if (r < 0) return TC_ESHAPE;                                       // strict mode (tests): a convolution it could not take
+    if (r > 0) {
+      TC_LAUNCH_CHECK();
+      return TC_OK;
+    }
+  }
   if (force == 0 && tc_gemm8_try(p, batch, s)) {                       // long-K / wide-N problems: 8-wave 256x256 ping-pong
     TC_LAUNCH_CHECK();
     return TC_OK;
