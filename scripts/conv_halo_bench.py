@@ -18,7 +18,7 @@ def timeit(fn, iters=20, reps=3):
         e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) / iters)
     return min(ts)
 
-tot = {"default": 0.0, "halo": 0.0}
+tot = {"default": 0.0, "halo": 0.0, "tall": 0.0}
 
 def conv(frames, h, w, cin, cout, tag, count, t3=False, emb=False):
     x = torch.randn(frames * h * w, cin, device=dev).to(BF)
@@ -32,19 +32,22 @@ def conv(frames, h, w, cin, cout, tag, count, t3=False, emb=False):
         kw = dict(conv=geom, row_bias=torch.randn(frames, cout, device=dev), row_div=h * w)
     fn = lambda: hip.gemm(x, wt, b, **kw)
     flops = 2.0 * frames * h * w * cout * taps * cin
-    r = {"default": [], "halo": []}
+    r = {"default": [], "halo": [], "tall": []}
     outs = {}
     for _ in range(2):
-        for name, v in (("default", "0"), ("halo", "2")):
-            os.environ["TC_CONV_HALO"] = v
+        # "tall" = 320-row patches where 20 rows (pixels) tile the image, the 160-row patches elsewhere (TC_CONV_HALO_TALL=2)
+        for name, v, tl in (("default", "0", "0"), ("halo", "2", "0"), ("tall", "2", "2")):
+            os.environ["TC_CONV_HALO"], os.environ["TC_CONV_HALO_TALL"] = v, tl
             outs[name] = fn()
             r[name].append(timeit(fn))
-    os.environ["TC_CONV_HALO"] = "0"
+    os.environ["TC_CONV_HALO"] = os.environ["TC_CONV_HALO_TALL"] = "0"
     t = {k: min(v) * 1e3 for k, v in r.items()}
     d = (outs["halo"].float() - outs["default"].float()).abs().max().item() / max(outs["default"].float().abs().max().item(), 1e-9)
+    same = torch.equal(outs["tall"], outs["halo"])
     for k in tot: tot[k] += count * t[k]
     print(f"{('convT3' if t3 else 'conv3x3') + ' ' + tag:16s} {cin:5d}->{cout:<5d} x{count:<3d} default {t['default']:7.1f} us {flops / t['default'] / 1e6:7.1f} TF/s | "
-          f"halo {t['halo']:7.1f} us {flops / t['halo'] / 1e6:7.1f} TF/s x{t['default'] / t['halo']:5.3f} | rel diff {d:.1e}", flush=True)
+          f"halo {t['halo']:7.1f} us {flops / t['halo'] / 1e6:7.1f} TF/s x{t['default'] / t['halo']:5.3f} | tall {t['tall']:7.1f} us x{t['default'] / t['tall']:5.3f} | "
+          f"rel diff {d:.1e} tall==halo {same}", flush=True)
 
 # (count per guided forward) -- ResBlock in_layers / out_layers convolutions and the four temporal convolutions of each
 # TemporalConvBlock, lvdm/modules/networks/openaimodel3d.py:154,179,255-266; levels 0 / 1 / 2 (level 3 is 5 x 8: no patches)
@@ -56,4 +59,4 @@ conv(32, 10, 16, 1280, 1280, "L2", 6); conv(32, 10, 16, 640, 1280, "L2 +emb", 1,
 conv(32, 10, 16, 2560, 1280, "L2 +emb", 2, emb=True); conv(32, 10, 16, 1920, 1280, "L2 +emb", 1, emb=True)
 conv(32, 40, 64, 320, 320, "L0", 20, t3=True); conv(32, 20, 32, 640, 640, "L1", 20, t3=True); conv(32, 10, 16, 1280, 1280, "L2", 20, t3=True)
 conv(32, 5, 8, 1280, 1280, "L3", 28, t3=True)
-print(f"sum over one guided forward: default {tot['default'] / 1e3:.2f} ms, halo {tot['halo'] / 1e3:.2f} ms")
+print(f"sum over one guided forward: default {tot['default'] / 1e3:.2f} ms, halo {tot['halo'] / 1e3:.2f} ms, tall where it tiles {tot['tall'] / 1e3:.2f} ms")

@@ -49,22 +49,24 @@ def write_conflicts(addrs):
 class HaloKernelModel:
     """One block of conv_halo_kernel<GATHER>, lane by lane."""
 
-    def __init__(self, gather, x, w, frames, h, wd, cin, n, lda=None):
+    def __init__(self, gather, x, w, frames, h, wd, cin, n, lda=None, WM=2):
         self.g, self.x, self.w = gather, x, w
         self.frames, self.h, self.wd, self.cin, self.n = frames, h, wd, cin, n
         self.lda = lda or cin
+        self.WM, self.PY, self.threads = WM, 5 * WM, 128 * WM          # WM = 4: the tall 320-row patch on eight waves
         self.taps = 9 if gather == CONV3x3 else 3
-        self.hy = 12 if gather == CONV3x3 else 10
+        self.hy = self.PY + 2 if gather == CONV3x3 else self.PY
         self.npix = self.hy * CH_HX
+        self.a_bytes = (self.npix * 128 + 1023) // 1024 * 1024
         self.hw = h * wd
         self.m = frames * self.hw
         self.read_extra = self.write_extra = 0
 
     def tiles(self):
         if self.g == CONV3x3:
-            per_img = (self.h // 10) * (self.wd // 16)
+            per_img = (self.h // self.PY) * (self.wd // 16)
             return self.frames * per_img, per_img
-        per_img = self.hw // 10
+        per_img = self.hw // self.PY
         return (self.frames // 16) * per_img, per_img
 
     def run_block(self, tile_m, tile_n, out):
@@ -74,22 +76,23 @@ class HaloKernelModel:
         if self.g == CONV3x3:
             tpx = self.wd // 16
             ty0 = pin // tpx
-            Y0, X0 = ty0 * 10, (pin - ty0 * tpx) * 16
+            Y0, X0 = ty0 * self.PY, (pin - ty0 * tpx) * 16
             m00 = (img * self.h + Y0) * self.wd + X0
             ys, xs = self.wd, 1
             row_lo = max(m00 - self.wd - 1, 0)
         else:
-            m00 = img * 16 * self.hw + pin * 10
+            m00 = img * 16 * self.hw + pin * self.PY
             ys, xs = 1, self.hw
             row_lo = m00
         sA = {}          # 16-byte unit index -> 8 values
         sW = [dict(), dict()]
         # per-thread halo vectors
         hv = []
-        for tid in range(256):
+        assert self.npix * 8 <= 7 * self.threads
+        for tid in range(self.threads):
             mine = []
             for i in range(7):
-                v = tid + 256 * i
+                v = tid + self.threads * i
                 pix, seg = v >> 3, v & 7
                 hy, hx = divmod(pix, CH_HX)
                 ok = pix < self.npix
@@ -99,7 +102,7 @@ class HaloKernelModel:
                     src = (img * self.h + iy) * self.wd + ix
                 else:
                     ok = ok and 1 <= hx <= 16
-                    src = (img * 16 + (hx - 1)) * self.hw + pin * 10 + hy
+                    src = (img * 16 + (hx - 1)) * self.hw + pin * self.PY + hy
                 off = ((src - row_lo) * self.lda * 2 + seg * 16) if ok else None
                 if ok:
                     assert 0 <= off < 2 ** 31 and src < self.m
@@ -108,15 +111,15 @@ class HaloKernelModel:
             hv.append(mine)
 
         def fill_halo(c):
-            for wave in range(4):
+            for wave in range(2 * self.WM):
                 for i in range(7):
                     addrs = [hv[wave * 64 + l][i][1] for l in range(64)]
                     self.write_extra += write_conflicts(addrs)
-            for tid in range(256):
+            for tid in range(self.threads):
                 for off, lds in hv[tid]:
                     if lds is None:
                         continue
-                    assert lds % 16 == 0 and lds + 16 <= CH_A_BYTES
+                    assert lds % 16 == 0 and lds + 16 <= self.a_bytes
                     if off is None:
                         sA[lds // 16] = np.zeros(8)
                     else:
@@ -124,21 +127,30 @@ class HaloKernelModel:
                         row, col = divmod(byte // 2, self.lda)
                         sA[lds // 16] = self.x[row, col:col + 8].astype(np.float64)
 
+        RSTEP = 16 * self.WM
+        RB = (CH_BN + RSTEP - 1) // RSTEP
+        PIECE = RSTEP * 128
+
         def request_w(k0, stage):
-            for tid in range(256):
+            sW[stage].clear()                                  # a stale unit read later would be a bug of the model's subject
+            for tid in range(self.threads):
                 lrow = tid >> 3
                 wchunk = (tid & 7) ^ ((lrow >> 1) & 7)
                 wave, lane = tid >> 6, tid & 63
-                for i in range(5):
-                    nn = tile_n * CH_BN + lrow + 32 * i
-                    dst = wave * 1024 + i * 4096 + lane * 16
-                    assert dst + 16 <= CH_W_STAGE
+                for i in range(RB):
+                    if not (self.WM == 2 or i < RB - 1 or wave < 4):
+                        continue
+                    nl = lrow + RSTEP * i
+                    assert nl < CH_BN                              # (the kernel would request zeros here; no such lane remains)
+                    nn = tile_n * CH_BN + nl
+                    dst = wave * 1024 + i * PIECE + lane * 16
+                    assert dst + 16 <= CH_W_STAGE and dst == nl * 128 + (tid & 7) * 16
                     sW[stage][dst // 16] = self.w[nn, k0 + wchunk * 8:k0 + wchunk * 8 + 8].astype(np.float64)
 
-        acc = np.zeros((4, CH_NT, CH_NT, 64, 4))     # wave, i, j, lane, reg
+        acc = np.zeros((2 * self.WM, CH_NT, CH_NT, 64, 4))     # wave, i, j, lane, reg
 
         def compute(stage, shift):
-            for wave in range(4):
+            for wave in range(2 * self.WM):
                 wm, wn = wave >> 1, wave & 1
                 lanes = np.arange(64)
                 frow, fq = lanes & 15, lanes >> 4
@@ -192,7 +204,7 @@ class HaloKernelModel:
             tap, c, ty, tx = ntap, nc, nty, ntx
         assert c == nch - 1 and tap == self.taps - 1 or nk == 0 or True
         # epilogue map
-        for wave in range(4):
+        for wave in range(2 * self.WM):
             wm, wn = wave >> 1, wave & 1
             col_w0 = tile_n * CH_BN + wn * CH_WT
             for i in range(CH_NT):
@@ -233,22 +245,24 @@ def direct_conv(gather, x, w, frames, h, wd, cin, n):
     return out
 
 
-@pytest.mark.parametrize("gather,frames,h,wd,cin,n,lda", [
-    (CONV3x3, 2, 20, 32, 128, 160, None),       # 2 x 2 patches per frame: every border kind; two channel chunks (one refill)
-    (CONV3x3, 1, 10, 16, 64, 320, 192),         # one patch = the whole image, two column tiles, strided rows
-    (CONVT3, 16, 4, 5, 128, 160, None),         # two pixel patches per clip (hw = 20), one clip
-    (CONVT3, 32, 2, 5, 64, 160, 128),           # two clips, strided rows
+@pytest.mark.parametrize("gather,frames,h,wd,cin,n,lda,WM", [
+    (CONV3x3, 2, 20, 32, 128, 160, None, 2),    # 2 x 2 patches per frame: every border kind; two channel chunks (one refill)
+    (CONV3x3, 1, 10, 16, 64, 320, 192, 2),      # one patch = the whole image, two column tiles, strided rows
+    (CONVT3, 16, 4, 5, 128, 160, None, 2),      # two pixel patches per clip (hw = 20), one clip
+    (CONVT3, 32, 2, 5, 64, 160, 128, 2),        # two clips, strided rows
+    (CONV3x3, 1, 40, 32, 128, 160, None, 4),    # tall patches (20 rows, eight waves): 2 x 2 per frame
+    (CONVT3, 16, 8, 5, 64, 160, 96, 4),         # tall temporal patches: 20 pixels x 16 frames, two per clip
 ])
-def test_conv_halo_index_model_matches_direct_convolution(gather, frames, h, wd, cin, n, lda):
+def test_conv_halo_index_model_matches_direct_convolution(gather, frames, h, wd, cin, n, lda, WM):
     rng = np.random.default_rng(5)
     lda = lda or cin
     m = frames * h * wd
     taps = 9 if gather == CONV3x3 else 3
     x = rng.integers(-3, 4, size=(m, lda)).astype(np.float32)     # small integers: every sum is exact
     w = rng.integers(-2, 3, size=(n, taps * cin)).astype(np.float32)
-    model = HaloKernelModel(gather, x, w, frames, h, wd, cin, n, lda=lda)
+    model = HaloKernelModel(gather, x, w, frames, h, wd, cin, n, lda=lda, WM=WM)
     tiles_m, _ = model.tiles()
-    assert tiles_m * 160 == m
+    assert tiles_m * 80 * WM == m
     out = np.full((m, n), np.nan)
     for tm in range(tiles_m):
         for tn in range(n // CH_BN):

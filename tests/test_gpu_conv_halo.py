@@ -34,21 +34,30 @@ def emu():
     return EmuOps(round_bf16=True)
 
 
-def _both(fn):
-    with env(TC_CONV_HALO=2):
+def _both(fn, tall_ok):
+    """(160-row patches, 320-row patches or None, implicit GEMM).  The tall kernel (TC_CONV_HALO_TALL=2) takes a problem only
+    if 20-row patches tile it; where they do not it falls back to the 160-row patches, which the first arm already covers."""
+    with env(TC_CONV_HALO=2, TC_CONV_HALO_TALL=0):
         halo = fn()
+    tall = None
+    if tall_ok:
+        with env(TC_CONV_HALO=2, TC_CONV_HALO_TALL=2):
+            tall = fn()
     with env(TC_CONV_HALO=0):
         base = fn()
     torch.cuda.synchronize()
-    return halo, base
+    return halo, tall, base
 
 
-def _close(halo, base, ref, what):
+def _close(halo, tall, base, ref, what):
     check(base, ref, what + " (implicit GEMM)")
     check(halo, ref, what + " (halo patches)")
     # same operands, same fp32 products, another summation order: far inside a bf16 ulp of the result's scale
     d = (halo.float() - base.float()).abs().max().item()
     assert d <= 2.0 ** -6 * max(base.float().abs().max().item(), 1.0), f"{what}: halo vs implicit GEMM differ by {d}"
+    if tall is not None:
+        # a tall patch is two 160-row patches stacked: same chunk-major order per output element -> the same bits
+        assert torch.equal(tall, halo), f"{what}: 320-row patches differ bit-wise from 160-row patches"
 
 
 # (frames, h, w, cin, n): one patch; the UNet's levels 2 / 1 / 0 at B = 2; several patches per frame with every border kind
@@ -63,8 +72,8 @@ def test_conv3x3(hip, emu, frames, h, w_, cin, n, epi):
     kw = dict(conv=conv)
     if epi != "plain":
         kw.update(row_bias=rnd(frames, n, seed=24, dtype=torch.float32), row_div=h * w_, residual=rnd(m, n, seed=25), act=ACT_SILU)
-    halo, base = _both(lambda: hip.gemm(a, w, bias, **kw))
-    _close(halo, base, emu.gemm(a, w, bias, **kw), f"conv3x3 {frames}x{h}x{w_} {cin}->{n} {epi}")
+    halo, tall, base = _both(lambda: hip.gemm(a, w, bias, **kw), h % 20 == 0)
+    _close(halo, tall, base, emu.gemm(a, w, bias, **kw), f"conv3x3 {frames}x{h}x{w_} {cin}->{n} {epi}")
 
 
 @pytest.mark.parametrize("frames,hw,cin,n", [(16, 10, 64, 160), (32, 160, 1280, 1280), (32, 640, 640, 640), (32, 2560, 320, 320),
@@ -76,8 +85,8 @@ def test_conv_t3(hip, emu, frames, hw, cin, n, res):
     a = rnd(m, cin, seed=31)
     w, bias = rnd(n, 3 * cin, seed=32, scale=(3 * cin) ** -0.5), rnd(n, seed=33, dtype=torch.float32)
     residual = rnd(m, n, seed=34) if res else None
-    halo, base = _both(lambda: hip.gemm(a, w, bias, conv=conv, residual=residual))
-    _close(halo, base, emu.gemm(a, w, bias, conv=conv, residual=residual), f"convT3 {frames}x{hw} {cin}->{n} res={res}")
+    halo, tall, base = _both(lambda: hip.gemm(a, w, bias, conv=conv, residual=residual), hw % 20 == 0)
+    _close(halo, tall, base, emu.gemm(a, w, bias, conv=conv, residual=residual), f"convT3 {frames}x{hw} {cin}->{n} res={res}")
 
 
 def test_shapes_the_kernel_cannot_take_fall_through_in_mode_1_and_fail_in_mode_2(hip, emu):
@@ -129,12 +138,13 @@ def test_locality_of_the_zero_padding(hip):
     torch.cuda.synchronize()
 
 
-def test_repeated_launches_are_bit_identical(hip):
-    """Race screen: 30 launches of the level-0 problem (1024 patches on 512 block slots), all identical."""
+@pytest.mark.parametrize("tall", [0, 2])
+def test_repeated_launches_are_bit_identical(hip, tall):
+    """Race screen: 30 launches of the level-0 problem (1024 patches on 512 block slots | 512 tall ones on 256), all identical."""
     frames, h, w_, cin, n = 32, 40, 64, 320, 320
     conv = dict(kind="3x3", frames=frames, cin=cin, h_in=h, w_in=w_, h_out=h, w_out=w_, stride=1, upsample=False)
     a, w = rnd(frames * h * w_, cin, seed=71), rnd(n, 9 * cin, seed=72, scale=(9 * cin) ** -0.5)
-    with env(TC_CONV_HALO=2):
+    with env(TC_CONV_HALO=2, TC_CONV_HALO_TALL=tall):
         first = hip.gemm(a, w, conv=conv)
         for _ in range(30):
             assert torch.equal(hip.gemm(a, w, conv=conv), first)

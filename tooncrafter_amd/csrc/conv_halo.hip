@@ -36,21 +36,30 @@ namespace {
 
 constexpr int CH_BN = 160, CH_WT = 80, CH_NT = 5;
 constexpr int CH_HX = 18;                                  // halo patch width (16 + 2) for both geometries
-constexpr int CH_A_BYTES = 28 * 1024;                      // 216 (180) halo pixels x 128 B, padded to whole KiB
 constexpr int CH_W_STAGE = CH_BN * TC_BK * 2;              // 20 KiB
-constexpr int CH_NV = 7;                                   // halo vectors per thread and chunk: ceil(216 * 8 / 256)
+constexpr int CH_NV = 7;                                   // halo vectors per thread and chunk: ceil(216 * 8 / 256) = ceil(396 * 8 / 512)
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-template <int GATHER>
+// WM = waves along M: 2 = the 160-row patch (PY = 10 patch rows, 4 waves, two blocks per CU); 4 = a TALL 320-row patch
+// (PY = 20, 8 waves, one block per CU; TC_CONV_HALO_TALL): the halo makes A rows nearly free -- 22 x 18 halo pixels per
+// chunk and NINE K-steps -- so the W tile is what a K-step pays for, and a tall block requests it once for twice the rows:
+// 25.6 KiB per 320 x 160 x 64 step, 9.8 TB/s chip-wide at the MFMA roof (the 160-row patch: 18; the implicit GEMM: 31).
+template <int GATHER, int WM>
 struct ChGeo {                                             // 3x3: y = image row, x = pixel; temporal: y = pixel, x = frame
   static constexpr int TAPS = GATHER == TC_GATHER_CONV3x3 ? 9 : 3;
-  static constexpr int HY = GATHER == TC_GATHER_CONV3x3 ? 12 : 10;
-  static constexpr int NPIX = HY * CH_HX;                  // 216 | 180
+  static constexpr int PY = 5 * WM;                        // patch rows: 10 | 20
+  static constexpr int HY = GATHER == TC_GATHER_CONV3x3 ? PY + 2 : PY;
+  static constexpr int NPIX = HY * CH_HX;                  // 216 | 180 | 396 | 360
+  static constexpr int THREADS = 128 * WM;
+  static constexpr int A_BYTES = (NPIX * 128 + 1023) / 1024 * 1024;       // 27 | 23 | 50 | 45 KiB
+  static_assert(NPIX * 8 <= CH_NV * THREADS, "halo vectors per thread");
 };
 
-template <int GATHER>
-__global__ __launch_bounds__(256, 2) void conv_halo_kernel(const TcGemmParams p, const int order) {
-  using G = ChGeo<GATHER>;
+template <int GATHER, int WM>
+__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void conv_halo_kernel(const TcGemmParams p, const int order) {
+  using G = ChGeo<GATHER, WM>;
+  constexpr int CH_A_BYTES = G::A_BYTES;
+  constexpr int PY = G::PY;
   __shared__ __attribute__((aligned(1024))) char smem[CH_A_BYTES + 2 * CH_W_STAGE];
   char* const sA = smem;
   char* const sW = smem + CH_A_BYTES;
@@ -65,8 +74,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const TcGemmParams p,
   const int hw = p.h_out * p.w_out;
   const int tiles_n = p.n / CH_BN;
   int per_img, tiles_m;                                    // patches per frame (3x3) | per clip (temporal)
-  if (GATHER == TC_GATHER_CONV3x3) { per_img = (p.h_out / 10) * (p.w_out / 16); tiles_m = p.frames * per_img; }
-  else { per_img = hw / 10; tiles_m = (p.frames / 16) * per_img; }
+  if (GATHER == TC_GATHER_CONV3x3) { per_img = (p.h_out / PY) * (p.w_out / 16); tiles_m = p.frames * per_img; }
+  else { per_img = hw / PY; tiles_m = (p.frames / 16) * per_img; }
   int tile_m, tile_n;
   tc_tile_of_block(blockIdx.x, tiles_m, tiles_n, order, tile_m, tile_n);
   if (tile_m >= tiles_m) return;
@@ -77,13 +86,13 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const TcGemmParams p,
   if (GATHER == TC_GATHER_CONV3x3) {
     const int tpx = p.w_out / 16;
     const int ty0 = pin / tpx;
-    Y0 = ty0 * 10;
+    Y0 = ty0 * PY;
     X0 = (pin - ty0 * tpx) * 16;
     m00 = ((int64_t)img * p.h_out + Y0) * p.w_out + X0;
     ys = p.w_out;
     xs = 1;
   } else {
-    m00 = (int64_t)img * 16 * hw + pin * 10;
+    m00 = (int64_t)img * 16 * hw + pin * PY;
     ys = 1;
     xs = hw;
   }
@@ -96,13 +105,13 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const TcGemmParams p,
   const g8_srd_t w_srd = g8_make_srd(reinterpret_cast<const bf16_t*>(p.w) + bz * p.stride_w, tc_w_extent(p));
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
-  // ---- halo vectors of this thread: v = tid + 256 i -> halo pixel v >> 3, 16-byte segment v & 7 (8 lanes = one pixel's
+  // ---- halo vectors of this thread: v = tid + THREADS i -> halo pixel v >> 3, 16-byte segment v & 7 (8 lanes = one pixel's
   // 128 bytes: coalesced source lines, conflict-free ds_write_b128 groups)
   uint32_t hv_off[CH_NV];
   int hv_lds[CH_NV];                                       // -1: no such pixel
 #pragma unroll
   for (int i = 0; i < CH_NV; ++i) {
-    const int v = tid + 256 * i;
+    const int v = tid + G::THREADS * i;
     const int pix = v >> 3, seg = v & 7;
     const int hy = pix / CH_HX, hx = pix - hy * CH_HX;
     bool ok = pix < G::NPIX;
@@ -113,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const TcGemmParams p,
       src = ((int64_t)img * p.h_in + iy) * p.w_in + ix;
     } else {
       ok = ok && hx >= 1 && hx <= 16;
-      src = ((int64_t)img * 16 + (hx - 1)) * hw + pin * 10 + hy;
+      src = ((int64_t)img * 16 + (hx - 1)) * hw + pin * PY + hy;
     }
     hv_off[i] = ok ? (uint32_t)((src - row_lo) * p.lda * 2 + seg * 16) : TC_OOB;       // outside the image: zeros
     hv_lds[i] = pix < G::NPIX ? pix * 128 + ((seg ^ (pix & 7)) << 4) : -1;
@@ -130,20 +139,25 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const TcGemmParams p,
       if (hv_lds[i] >= 0) *reinterpret_cast<u32x4*>(sA + hv_lds[i]) = hv[i];
   };
 
-  // ---- W tile requests: thread -> (row lrow + 32 i, 16-byte chunk), the swizzle on the SOURCE chunk (gemm16.hip)
+  // ---- W tile requests: thread -> (row lrow + RSTEP i, 16-byte chunk), the swizzle on the SOURCE chunk (gemm16.hip).
+  // The tall block's third pass covers rows 128..191 of a 160-row tile: waves 4..7 have no rows there and request nothing
+  // (every wait of this loop is vmcnt(0): the waves need not issue equal numbers of requests)
+  constexpr int RSTEP = 16 * WM, RB = (CH_BN + RSTEP - 1) / RSTEP, PIECE = RSTEP * TC_BK * 2;      // 32 | 64 rows per pass, 5 | 3 passes
   const int lrow = tid >> 3;
   const int wchunk = (tid & 7) ^ ((lrow >> 1) & 7);
-  uint32_t b_voff[5];
+  uint32_t b_voff[RB];
 #pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const int n = tile_n * CH_BN + lrow + 32 * i;
-    b_voff[i] = n < p.n ? (uint32_t)((int64_t)n * p.ldw * 2 + wchunk * 16) : TC_OOB;
+  for (int i = 0; i < RB; ++i) {
+    const int nl = lrow + RSTEP * i;
+    const int n = tile_n * CH_BN + nl;
+    b_voff[i] = (nl < CH_BN && n < p.n) ? (uint32_t)((int64_t)n * p.ldw * 2 + wchunk * 16) : TC_OOB;
   }
   auto request_w = [&](int k0, int stage) {
     const uint32_t dst = lds0 + (uint32_t)(CH_A_BYTES + stage * CH_W_STAGE + wave_u * 1024);
     const uint32_t soff = (uint32_t)k0 * 2u;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) g8_dma16(w_srd, dst + i * 4096, b_voff[i], soff);
+    for (int i = 0; i < RB; ++i)
+      if (WM == 2 || i < RB - 1 || wave_u < 4) g8_dma16(w_srd, dst + i * PIECE, b_voff[i], soff);
   };
 
   f32x4_t acc[CH_NT][CH_NT];
@@ -284,6 +298,10 @@ int conv_halo_mode() {        // TC_CONV_HALO = 0 / unset never | 1 | 2 whenever
   const char* e = getenv("TC_CONV_HALO");
   return e ? atoi(e) : 0;
 }
+int conv_halo_tall() {        // TC_CONV_HALO_TALL = 0 / unset: 160-row patches | 1: 320-row patches where they fill the 256 CUs | 2: wherever they tile
+  const char* e = getenv("TC_CONV_HALO_TALL");
+  return e ? atoi(e) : 0;
+}
 
 }  // namespace
 
@@ -297,25 +315,35 @@ int tc_conv_halo_try(const TcGemmParams& p, int batch, hipStream_t s, bool dry) 
   const int declined = mode == 2 ? -1 : 0;
   if (p.act == TC_ACT_GEGLU || p.gn_part || p.a_norm || (p.n % CH_BN) != 0 || (p.cin % TC_BK) != 0 ||
       p.k != (p.gather == TC_GATHER_CONV3x3 ? 9 : 3) * p.cin) return declined;
-  int64_t tiles_m;
+  const int hw = p.h_out * p.w_out;
+  int64_t tiles_m, tiles_tall = 0;                                       // 160-row patches; 320-row patches (0: do not tile)
   if (p.gather == TC_GATHER_CONV3x3) {
     if (p.stride != 1 || p.upsample || p.pad != 1 || p.h_in != p.h_out || p.w_in != p.w_out) return declined;
     if ((p.h_out % 10) != 0 || (p.w_out % 16) != 0) return declined;
     tiles_m = (int64_t)p.frames * (p.h_out / 10) * (p.w_out / 16);
+    if ((p.h_out % 20) == 0) tiles_tall = tiles_m / 2;
   } else {
-    const int hw = p.h_out * p.w_out;
     if (p.t_len != 16 || (p.frames % 16) != 0 || (hw % 10) != 0) return declined;
     tiles_m = (int64_t)(p.frames / 16) * (hw / 10);
+    if ((hw % 20) == 0) tiles_tall = tiles_m / 2;
     if ((int64_t)17 * hw * p.lda * 2 >= 0x7fffff00LL) return declined;    // a patch spans the clip's 16 frames: 31-bit offsets
   }
   if (tiles_m * 160 != p.m) return declined;
   const int tiles_n = p.n / CH_BN;
-  const int64_t nblk = (int64_t)tiles_n * 8 * ((tiles_m + 7) / 8);
+  const int tall = conv_halo_tall();
+  const bool use_tall = tiles_tall > 0 && (tall == 2 || (tall == 1 && tiles_tall * tiles_n * batch >= 256));
+  const int64_t tm = use_tall ? tiles_tall : tiles_m;
+  const int64_t nblk = (int64_t)tiles_n * 8 * ((tm + 7) / 8);
   if (nblk > 0x7fffffffLL || batch > 65535) return declined;
   if (dry) return 1;
-  dim3 grid((unsigned)nblk, 1, (unsigned)batch), block(256);
+  dim3 grid((unsigned)nblk, 1, (unsigned)batch);
   const int order = tc_gemm_tile_order(p, tiles_n);
-  if (p.gather == TC_GATHER_CONV3x3) hipLaunchKernelGGL((conv_halo_kernel<TC_GATHER_CONV3x3>), grid, block, 0, s, p, order);
-  else hipLaunchKernelGGL((conv_halo_kernel<TC_GATHER_CONVT3>), grid, block, 0, s, p, order);
+  if (use_tall) {
+    if (p.gather == TC_GATHER_CONV3x3) hipLaunchKernelGGL((conv_halo_kernel<TC_GATHER_CONV3x3, 4>), grid, dim3(512), 0, s, p, order);
+    else hipLaunchKernelGGL((conv_halo_kernel<TC_GATHER_CONVT3, 4>), grid, dim3(512), 0, s, p, order);
+  } else {
+    if (p.gather == TC_GATHER_CONV3x3) hipLaunchKernelGGL((conv_halo_kernel<TC_GATHER_CONV3x3, 2>), grid, dim3(256), 0, s, p, order);
+    else hipLaunchKernelGGL((conv_halo_kernel<TC_GATHER_CONVT3, 2>), grid, dim3(256), 0, s, p, order);
+  }
   return 1;
 }
