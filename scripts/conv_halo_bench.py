@@ -18,7 +18,7 @@ def timeit(fn, iters=20, reps=3):
         e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) / iters)
     return min(ts)
 
-tot = {"default": 0.0, "halo": 0.0, "tall": 0.0}
+tot = {"default": 0.0, "halo": 0.0, "halo1g": 0.0, "tall": 0.0}
 
 def conv(frames, h, w, cin, cout, tag, count, t3=False, emb=False):
     x = torch.randn(frames * h * w, cin, device=dev).to(BF)
@@ -32,21 +32,23 @@ def conv(frames, h, w, cin, cout, tag, count, t3=False, emb=False):
         kw = dict(conv=geom, row_bias=torch.randn(frames, cout, device=dev), row_div=h * w)
     fn = lambda: hip.gemm(x, wt, b, **kw)
     flops = 2.0 * frames * h * w * cout * taps * cin
-    r = {"default": [], "halo": [], "tall": []}
+    r = {"default": [], "halo": [], "halo1g": [], "tall": []}
     outs = {}
     for _ in range(2):
         # "tall" = 320-row patches where 20 rows (pixels) tile the image, the 160-row patches elsewhere (TC_CONV_HALO_TALL=2)
-        for name, v, tl in (("default", "0", "0"), ("halo", "2", "0"), ("tall", "2", "2")):
-            os.environ["TC_CONV_HALO"], os.environ["TC_CONV_HALO_TALL"] = v, tl
+        # "halo" = 160-row patches, K split over two groups inside the block where the launch has at most 256 blocks
+        # (TC_CONV_HALO_KSPLIT=1, level 2); "halo1g" = never split
+        for name, v, tl, ks in (("default", "0", "0", "1"), ("halo", "2", "0", "1"), ("halo1g", "2", "0", "0"), ("tall", "2", "2", "1")):
+            os.environ["TC_CONV_HALO"], os.environ["TC_CONV_HALO_TALL"], os.environ["TC_CONV_HALO_KSPLIT"] = v, tl, ks
             outs[name] = fn()
             r[name].append(timeit(fn))
-    os.environ["TC_CONV_HALO"] = os.environ["TC_CONV_HALO_TALL"] = "0"
+    os.environ["TC_CONV_HALO"] = os.environ["TC_CONV_HALO_TALL"] = "0"; os.environ["TC_CONV_HALO_KSPLIT"] = "1"
     t = {k: min(v) * 1e3 for k, v in r.items()}
     d = (outs["halo"].float() - outs["default"].float()).abs().max().item() / max(outs["default"].float().abs().max().item(), 1e-9)
-    same = torch.equal(outs["tall"], outs["halo"])
+    same = torch.equal(outs["tall"], outs["halo1g"])
     for k in tot: tot[k] += count * t[k]
     print(f"{('convT3' if t3 else 'conv3x3') + ' ' + tag:16s} {cin:5d}->{cout:<5d} x{count:<3d} default {t['default']:7.1f} us {flops / t['default'] / 1e6:7.1f} TF/s | "
-          f"halo {t['halo']:7.1f} us {flops / t['halo'] / 1e6:7.1f} TF/s x{t['default'] / t['halo']:5.3f} | tall {t['tall']:7.1f} us x{t['default'] / t['tall']:5.3f} | "
+          f"halo {t['halo']:7.1f} us {flops / t['halo'] / 1e6:7.1f} TF/s x{t['default'] / t['halo']:5.3f} | one group {t['halo1g']:7.1f} | tall {t['tall']:7.1f} us x{t['default'] / t['tall']:5.3f} | "
           f"rel diff {d:.1e} tall==halo {same}", flush=True)
 
 # (count per guided forward) -- ResBlock in_layers / out_layers convolutions and the four temporal convolutions of each

@@ -49,11 +49,13 @@ def write_conflicts(addrs):
 class HaloKernelModel:
     """One block of conv_halo_kernel<GATHER>, lane by lane."""
 
-    def __init__(self, gather, x, w, frames, h, wd, cin, n, lda=None, WM=2):
+    def __init__(self, gather, x, w, frames, h, wd, cin, n, lda=None, WM=2, KS=1):
         self.g, self.x, self.w = gather, x, w
         self.frames, self.h, self.wd, self.cin, self.n = frames, h, wd, cin, n
         self.lda = lda or cin
         self.WM, self.PY, self.threads = WM, 5 * WM, 128 * WM          # WM = 4: the tall 320-row patch on eight waves
+        self.KS = KS                                                    # KS = 2: two 4-wave groups, each with half of the channel chunks
+        assert KS == 1 or (WM == 2 and (cin // TC_BK) % 2 == 0)
         self.taps = 9 if gather == CONV3x3 else 3
         self.hy = self.PY + 2 if gather == CONV3x3 else self.PY
         self.npix = self.hy * CH_HX
@@ -182,27 +184,33 @@ class HaloKernelModel:
                                 for r in range(4):
                                     acc[wave, i, j, l, r] += D[4 * (l >> 4) + r, l & 15]
 
-        nch = self.cin // TC_BK
-        nk = self.taps * nch
-        request_w(0, 0)
-        fill_halo(0)
-        c = tap = ty = tx = 0
-        for kb in range(nk):
-            st = kb & 1
-            ntap, nc, nty, ntx = tap + 1, c, ty, tx + 1
-            if ntx == 3:
-                ntx, nty = 0, ty + 1
-            if ntap == self.taps:
-                ntap, nc, nty, ntx = 0, c + 1, 0, 0
-            more = kb + 1 < nk
-            refill = more and ntap == 0
-            if more:
-                request_w(ntap * self.cin + nc * TC_BK, st ^ 1)
-            compute(st, ty * CH_HX + tx if self.g == CONV3x3 else tx)
-            if refill:
-                fill_halo(nc)
-            tap, c, ty, tx = ntap, nc, nty, ntx
-        assert c == nch - 1 and tap == self.taps - 1 or nk == 0 or True
+        nch = (self.cin // TC_BK) // self.KS
+        total = np.zeros_like(acc)
+        for grp in range(self.KS):                 # the groups own separate LDS buffers: run one after the other on fresh state
+            sA.clear(); sW[0].clear(); sW[1].clear(); acc[...] = 0.0
+            c0 = grp * nch
+            nk = self.taps * nch
+            request_w(c0 * TC_BK, 0)
+            fill_halo(c0)
+            c = tap = ty = tx = 0
+            for kb in range(nk):
+                st = kb & 1
+                ntap, nc, nty, ntx = tap + 1, c, ty, tx + 1
+                if ntx == 3:
+                    ntx, nty = 0, ty + 1
+                if ntap == self.taps:
+                    ntap, nc, nty, ntx = 0, c + 1, 0, 0
+                more = kb + 1 < nk
+                refill = more and ntap == 0
+                if more:
+                    request_w(ntap * self.cin + (c0 + nc) * TC_BK, st ^ 1)
+                compute(st, ty * CH_HX + tx if self.g == CONV3x3 else tx)
+                if refill:
+                    fill_halo(c0 + nc)
+                tap, c, ty, tx = ntap, nc, nty, ntx
+            assert c == nch and tap == 0            # the counters have stepped past the last (chunk, tap)
+            total += acc                            # group 1 hands its accumulators to group 0: acc0 + acc1
+        acc = total
         # epilogue map
         for wave in range(2 * self.WM):
             wm, wn = wave >> 1, wave & 1
@@ -245,22 +253,24 @@ def direct_conv(gather, x, w, frames, h, wd, cin, n):
     return out
 
 
-@pytest.mark.parametrize("gather,frames,h,wd,cin,n,lda,WM", [
-    (CONV3x3, 2, 20, 32, 128, 160, None, 2),    # 2 x 2 patches per frame: every border kind; two channel chunks (one refill)
-    (CONV3x3, 1, 10, 16, 64, 320, 192, 2),      # one patch = the whole image, two column tiles, strided rows
-    (CONVT3, 16, 4, 5, 128, 160, None, 2),      # two pixel patches per clip (hw = 20), one clip
-    (CONVT3, 32, 2, 5, 64, 160, 128, 2),        # two clips, strided rows
-    (CONV3x3, 1, 40, 32, 128, 160, None, 4),    # tall patches (20 rows, eight waves): 2 x 2 per frame
-    (CONVT3, 16, 8, 5, 64, 160, 96, 4),         # tall temporal patches: 20 pixels x 16 frames, two per clip
+@pytest.mark.parametrize("gather,frames,h,wd,cin,n,lda,WM,KS", [
+    (CONV3x3, 2, 20, 32, 128, 160, None, 2, 1),    # 2 x 2 patches per frame: every border kind; two channel chunks (one refill)
+    (CONV3x3, 1, 10, 16, 64, 320, 192, 2, 1),      # one patch = the whole image, two column tiles, strided rows
+    (CONVT3, 16, 4, 5, 128, 160, None, 2, 1),      # two pixel patches per clip (hw = 20), one clip
+    (CONVT3, 32, 2, 5, 64, 160, 128, 2, 1),        # two clips, strided rows
+    (CONV3x3, 1, 40, 32, 128, 160, None, 4, 1),    # tall patches (20 rows, eight waves): 2 x 2 per frame
+    (CONVT3, 16, 8, 5, 64, 160, 96, 4, 1),         # tall temporal patches: 20 pixels x 16 frames, two per clip
+    (CONV3x3, 1, 10, 32, 256, 160, None, 2, 2),    # K split over two groups: chunks {0, 1} | {2, 3}, a refill in each
+    (CONVT3, 16, 2, 5, 128, 160, 160, 2, 2),       # ... temporal: one chunk per group
 ])
-def test_conv_halo_index_model_matches_direct_convolution(gather, frames, h, wd, cin, n, lda, WM):
+def test_conv_halo_index_model_matches_direct_convolution(gather, frames, h, wd, cin, n, lda, WM, KS):
     rng = np.random.default_rng(5)
     lda = lda or cin
     m = frames * h * wd
     taps = 9 if gather == CONV3x3 else 3
     x = rng.integers(-3, 4, size=(m, lda)).astype(np.float32)     # small integers: every sum is exact
     w = rng.integers(-2, 3, size=(n, taps * cin)).astype(np.float32)
-    model = HaloKernelModel(gather, x, w, frames, h, wd, cin, n, lda=lda, WM=WM)
+    model = HaloKernelModel(gather, x, w, frames, h, wd, cin, n, lda=lda, WM=WM, KS=KS)
     tiles_m, _ = model.tiles()
     assert tiles_m * 80 * WM == m
     out = np.full((m, n), np.nan)

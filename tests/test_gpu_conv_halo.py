@@ -37,11 +37,11 @@ def emu():
 def _both(fn, tall_ok):
     """(160-row patches, 320-row patches or None, implicit GEMM).  The tall kernel (TC_CONV_HALO_TALL=2) takes a problem only
     if 20-row patches tile it; where they do not it falls back to the 160-row patches, which the first arm already covers."""
-    with env(TC_CONV_HALO=2, TC_CONV_HALO_TALL=0):
+    with env(TC_CONV_HALO=2, TC_CONV_HALO_TALL=0, TC_CONV_HALO_KSPLIT=0):
         halo = fn()
     tall = None
     if tall_ok:
-        with env(TC_CONV_HALO=2, TC_CONV_HALO_TALL=2):
+        with env(TC_CONV_HALO=2, TC_CONV_HALO_TALL=2, TC_CONV_HALO_KSPLIT=0):
             tall = fn()
     with env(TC_CONV_HALO=0):
         base = fn()
@@ -87,6 +87,32 @@ def test_conv_t3(hip, emu, frames, hw, cin, n, res):
     residual = rnd(m, n, seed=34) if res else None
     halo, tall, base = _both(lambda: hip.gemm(a, w, bias, conv=conv, residual=residual), hw % 20 == 0)
     _close(halo, tall, base, emu.gemm(a, w, bias, conv=conv, residual=residual), f"convT3 {frames}x{hw} {cin}->{n} res={res}")
+
+
+@pytest.mark.parametrize("kind,frames,h,w_,cin,n", [("3x3", 32, 10, 16, 1280, 1280), ("3x3", 2, 10, 16, 256, 160), ("3x3", 3, 20, 32, 640, 320),
+                                                     ("t3", 32, 10, 16, 1280, 1280), ("t3", 16, 2, 5, 128, 160), ("t3", 32, 8, 20, 384, 320)])
+def test_k_split_inside_the_block(hip, emu, kind, frames, h, w_, cin, n):
+    """TC_CONV_HALO_KSPLIT: two 4-wave groups with half of the channel chunks each, accumulators handed over through LDS.
+    0 = never, 2 = whenever cin / 64 is even (forced here also where the patches would fill the chip)."""
+    if kind == "3x3":
+        conv = dict(kind="3x3", frames=frames, cin=cin, h_in=h, w_in=w_, h_out=h, w_out=w_, stride=1, upsample=False)
+    else:
+        conv = dict(kind="t3", frames=frames, t_len=16, cin=cin, h_out=h, w_out=w_)
+    taps = 9 if kind == "3x3" else 3
+    m = frames * h * w_
+    a = rnd(m, cin, seed=81)
+    w, bias = rnd(n, taps * cin, seed=82, scale=(taps * cin) ** -0.5), rnd(n, seed=83, dtype=torch.float32)
+    residual = rnd(m, n, seed=84)
+    out = {}
+    for ks in (0, 2):
+        with env(TC_CONV_HALO=2, TC_CONV_HALO_TALL=0, TC_CONV_HALO_KSPLIT=ks):
+            out[ks] = hip.gemm(a, w, bias, conv=conv, residual=residual)
+    torch.cuda.synchronize()
+    ref = emu.gemm(a, w, bias, conv=conv, residual=residual)
+    check(out[0], ref, f"halo {kind} {frames}x{h}x{w_} {cin}->{n}, one group")
+    check(out[2], ref, f"halo {kind} {frames}x{h}x{w_} {cin}->{n}, K split over two groups")
+    d = (out[2].float() - out[0].float()).abs().max().item()
+    assert d <= 2.0 ** -6 * max(out[0].float().abs().max().item(), 1.0), f"K split vs one group differ by {d}"
 
 
 def test_shapes_the_kernel_cannot_take_fall_through_in_mode_1_and_fail_in_mode_2(hip, emu):

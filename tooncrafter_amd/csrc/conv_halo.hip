@@ -55,20 +55,35 @@ struct ChGeo {                                             // 3x3: y = image row
   static_assert(NPIX * 8 <= CH_NV * THREADS, "halo vectors per thread");
 };
 
-template <int GATHER, int WM>
-__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void conv_halo_kernel(const TcGemmParams p, const int order) {
+// KS = 2 (TC_CONV_HALO_KSPLIT, WM = 2 only): the K loop split over TWO 4-wave groups inside one 8-wave block -- for the
+// launches whose patches do not fill the chip (level 2: 256 tiles on 256 CUs = one 4-wave block per CU, one MFMA wave per
+// SIMD, which reaches 45 % of the matrix pipe where two reach 70 %: DESIGN.md 5.5).  Group g owns the channel chunks
+// [g nch / 2, (g + 1) nch / 2) with its OWN halo buffer and W stages (2 x 68 KiB of LDS), both groups run the same loop in
+// lockstep (the barriers are the block's), and at the end group 1 hands its accumulators to group 0 through LDS (fixed
+// order: acc0 + acc1), which runs the epilogue.  Unlike the split over blocks (TC_GEMM_SPLITK) no fp32 partial tile
+// reaches memory and no second kernel runs.
+constexpr int CH_RED_OFF = 32 * 1024;                      // the hand-over area starts behind group 0's epilogue slabs
+constexpr int CH_RED_BYTES = 4 * CH_NT * CH_NT * 4 * 64 * 4;       // 4 waves x 25 MFMA tiles x 4 registers x 64 lanes x fp32 = 100 KiB
+
+template <int GATHER, int WM, int KS>
+__global__ __launch_bounds__(128 * WM * KS, (WM == 2 && KS == 1) ? 2 : 1) void conv_halo_kernel(const TcGemmParams p, const int order) {
   using G = ChGeo<GATHER, WM>;
+  static_assert(KS == 1 || WM == 2, "the K split runs two 4-wave groups");
   constexpr int CH_A_BYTES = G::A_BYTES;
   constexpr int PY = G::PY;
-  __shared__ __attribute__((aligned(1024))) char smem[CH_A_BYTES + 2 * CH_W_STAGE];
-  char* const sA = smem;
-  char* const sW = smem + CH_A_BYTES;
+  constexpr int GROUP_BYTES = CH_A_BYTES + 2 * CH_W_STAGE;
+  constexpr int SMEM_BYTES = KS == 1 ? GROUP_BYTES : (KS * GROUP_BYTES > CH_RED_OFF + CH_RED_BYTES ? KS * GROUP_BYTES : CH_RED_OFF + CH_RED_BYTES);
+  __shared__ __attribute__((aligned(1024))) char smem[SMEM_BYTES];
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int lane = threadIdx.x & 63;
+  const int grp = KS == 1 ? 0 : (int)threadIdx.x / G::THREADS;            // wave-uniform: a group is four whole waves
+  const int grp_u = __builtin_amdgcn_readfirstlane(grp);
+  const int tid = threadIdx.x - grp * G::THREADS;                         // thread within its group
+  const int wave = tid >> 6;                                              // wave within its group
   const int wm = wave >> 1, wn = wave & 1;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  char* const sA = smem + grp_u * GROUP_BYTES;
+  char* const sW = sA + CH_A_BYTES;
 
   // ---- block -> patch
   const int hw = p.h_out * p.w_out;
@@ -103,7 +118,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void conv_halo_kernel(co
   const int64_t bz = blockIdx.z;
   const tc_rsrc_t a_rsrc = tc_a_rsrc(p, bz, row_lo);
   const g8_srd_t w_srd = g8_make_srd(reinterpret_cast<const bf16_t*>(p.w) + bz * p.stride_w, tc_w_extent(p));
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (uint32_t)(grp_u * GROUP_BYTES);
 
   // ---- halo vectors of this thread: v = tid + THREADS i -> halo pixel v >> 3, 16-byte segment v & 7 (8 lanes = one pixel's
   // 128 bytes: coalesced source lines, conflict-free ds_write_b128 groups)
@@ -202,10 +217,11 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void conv_halo_kernel(co
   };
 
   // ---- K loop, chunk-major: step kb = (chunk c, tap t); W(kb + 1) is requested while step kb computes
-  const int nch = p.cin / TC_BK;
+  const int nch = (p.cin / TC_BK) / KS;                    // chunks of this group (KS = 2: cin / 64 is even -- host)
+  const int c0 = grp_u * nch;                              // its first chunk
   const int nk = G::TAPS * nch;
-  request_w(0, 0);
-  load_halo(0);
+  request_w(c0 * TC_BK, 0);
+  load_halo(c0);
   store_halo();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -217,8 +233,8 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void conv_halo_kernel(co
     if (ntap == G::TAPS) { ntap = 0; nc = c + 1; nty = 0; ntx = 0; }
     const bool more = kb + 1 < nk;
     const bool refill = more && ntap == 0;                 // block-uniform: the next step opens a new channel chunk
-    if (more) request_w(ntap * p.cin + nc * TC_BK, st ^ 1);
-    if (refill) load_halo(nc);
+    if (more) request_w(ntap * p.cin + (c0 + nc) * TC_BK, st ^ 1);
+    if (refill) load_halo(c0 + nc);
     compute(st, GATHER == TC_GATHER_CONV3x3 ? ty * CH_HX + tx : tx);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // own pieces of W(kb + 1) (and the halo vectors) have landed
     __syncthreads();                                       // every wave's fragment reads of this step are done
@@ -227,6 +243,27 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void conv_halo_kernel(co
       __syncthreads();
     }
     tap = ntap; c = nc; ty = nty; tx = ntx;
+  }
+
+  if (KS == 2) {
+    // group 1 -> group 0: [wave][tile][register][lane] fp32, a lane's values 256 bytes apart (conflict-free both ways)
+    float* red = reinterpret_cast<float*>(smem + CH_RED_OFF) + wave * (CH_NT * CH_NT * 4 * 64) + lane;
+    if (grp_u == 1) {
+#pragma unroll
+      for (int i = 0; i < CH_NT; ++i)
+#pragma unroll
+        for (int j = 0; j < CH_NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[((i * CH_NT + j) * 4 + r) * 64] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (grp_u == 1) return;
+#pragma unroll
+    for (int i = 0; i < CH_NT; ++i)
+#pragma unroll
+      for (int j = 0; j < CH_NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] += red[((i * CH_NT + j) * 4 + r) * 64];
   }
 
   // ---- epilogue: per wave, five passes of one 16-row MFMA block through a private fp32 slab [16][80] (gemm16.hip),
@@ -298,6 +335,10 @@ int conv_halo_mode() {        // TC_CONV_HALO = 0 / unset never | 1 | 2 whenever
   const char* e = getenv("TC_CONV_HALO");
   return e ? atoi(e) : 0;
 }
+int conv_halo_ksplit() {      // TC_CONV_HALO_KSPLIT = 0: never | 1 / unset: launches of at most 256 patches-blocks (one per CU) | 2: whenever cin / 64 is even
+  const char* e = getenv("TC_CONV_HALO_KSPLIT");
+  return e ? atoi(e) : 1;
+}
 int conv_halo_tall() {        // TC_CONV_HALO_TALL = 0 / unset: 160-row patches | 1: 320-row patches where they fill the 256 CUs | 2: wherever they tile
   const char* e = getenv("TC_CONV_HALO_TALL");
   return e ? atoi(e) : 0;
@@ -338,12 +379,19 @@ int tc_conv_halo_try(const TcGemmParams& p, int batch, hipStream_t s, bool dry) 
   if (dry) return 1;
   dim3 grid((unsigned)nblk, 1, (unsigned)batch);
   const int order = tc_gemm_tile_order(p, tiles_n);
+  const int ksm = conv_halo_ksplit();
+  const int nchunks = p.cin / TC_BK;
+  const bool ksplit = !use_tall && (nchunks % 2) == 0 && nchunks >= 4 &&
+                      (ksm == 2 || (ksm == 1 && tiles_m * tiles_n * batch <= 256));
   if (use_tall) {
-    if (p.gather == TC_GATHER_CONV3x3) hipLaunchKernelGGL((conv_halo_kernel<TC_GATHER_CONV3x3, 4>), grid, dim3(512), 0, s, p, order);
-    else hipLaunchKernelGGL((conv_halo_kernel<TC_GATHER_CONVT3, 4>), grid, dim3(512), 0, s, p, order);
+    if (p.gather == TC_GATHER_CONV3x3) hipLaunchKernelGGL((conv_halo_kernel<TC_GATHER_CONV3x3, 4, 1>), grid, dim3(512), 0, s, p, order);
+    else hipLaunchKernelGGL((conv_halo_kernel<TC_GATHER_CONVT3, 4, 1>), grid, dim3(512), 0, s, p, order);
+  } else if (ksplit) {
+    if (p.gather == TC_GATHER_CONV3x3) hipLaunchKernelGGL((conv_halo_kernel<TC_GATHER_CONV3x3, 2, 2>), grid, dim3(512), 0, s, p, order);
+    else hipLaunchKernelGGL((conv_halo_kernel<TC_GATHER_CONVT3, 2, 2>), grid, dim3(512), 0, s, p, order);
   } else {
-    if (p.gather == TC_GATHER_CONV3x3) hipLaunchKernelGGL((conv_halo_kernel<TC_GATHER_CONV3x3, 2>), grid, dim3(256), 0, s, p, order);
-    else hipLaunchKernelGGL((conv_halo_kernel<TC_GATHER_CONVT3, 2>), grid, dim3(256), 0, s, p, order);
+    if (p.gather == TC_GATHER_CONV3x3) hipLaunchKernelGGL((conv_halo_kernel<TC_GATHER_CONV3x3, 2, 1>), grid, dim3(256), 0, s, p, order);
+    else hipLaunchKernelGGL((conv_halo_kernel<TC_GATHER_CONVT3, 2, 1>), grid, dim3(256), 0, s, p, order);
   }
   return 1;
 }
