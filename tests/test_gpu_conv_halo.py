@@ -90,7 +90,7 @@ def test_conv_t3(hip, emu, frames, hw, cin, n, res):
 
 
 @pytest.mark.parametrize("kind,frames,h,w_,cin,n", [("3x3", 32, 10, 16, 1280, 1280), ("3x3", 2, 10, 16, 256, 160), ("3x3", 3, 20, 32, 640, 320),
-                                                     ("t3", 32, 10, 16, 1280, 1280), ("t3", 16, 2, 5, 128, 160), ("t3", 32, 8, 20, 384, 320)])
+                                                     ("t3", 32, 10, 16, 1280, 1280), ("t3", 16, 2, 5, 256, 160), ("t3", 32, 8, 20, 384, 320)])
 def test_k_split_inside_the_block(hip, emu, kind, frames, h, w_, cin, n):
     """TC_CONV_HALO_KSPLIT: two 4-wave groups with half of the channel chunks each, accumulators handed over through LDS.
     0 = never, 2 = whenever cin / 64 is even (forced here also where the patches would fill the chip)."""
