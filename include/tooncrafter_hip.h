@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TC_ABI_VERSION 9
+#define TC_ABI_VERSION 10
 
 enum {
   TC_OK = 0,
@@ -227,6 +227,23 @@ int tc_groupnorm(const tc_bf16* x, tc_bf16* y, const float* gamma, const float* 
 int tc_groupnorm_part(const tc_bf16* x, tc_bf16* y, const float* gamma, const float* beta, const float* part,
                       int32_t part_rows, int32_t samples, int32_t rows, int32_t c, float eps, int32_t silu,
                       void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ABI 10 -- GroupNorm(+SiLU) as a PROLOGUE of the convolution that consumes it (lvdm/basics.py:76-87 in front of
+ * lvdm/modules/networks/openaimodel3d.py:154,179 [ResBlock in_layers / out_layers] and :255-266 [TemporalConvBlock]): every
+ * GroupNorm of those blocks feeds a 3x3 / (3,1,1) convolution, so the normalised tensor need not exist.
+ *   tc_groupnorm_scale_shift: the statistics pass alone; scale_shift [samples][2][c] fp32 = per (sample, channel)
+ *     scale = rstd * gamma and shift = beta - mean * scale.  workspace: tc_groupnorm_workspace() bytes.
+ *   tc_conv_gn_bf16: C = epilogue(conv(act(x * scale + shift)) ...) -- TcGemmParams as for tc_gemm_bf16 (gather CONV3x3
+ *     stride 1 / pad 1 or CONVT3; a = the UN-normalised x), act = SiLU if silu else identity, rounded to bf16 exactly where
+ *     tc_groupnorm would have stored it; zero padding applies to the activation (outside the image the operand is 0).
+ *     gn_rows = output rows per GroupNorm sample (H*W for per-frame statistics, T*H*W for clip-wide ones).  Taken only by
+ *     the tap-reuse kernel (csrc/conv_halo.hip): TC_ESHAPE for anything tc_conv_gn_eligible refuses -- the caller then runs
+ *     tc_groupnorm + tc_gemm_bf16.  OPT-IN on the host side (TC_GN_FUSE=1); see DESIGN.md 5.5 (12). */
+int tc_groupnorm_scale_shift(const tc_bf16* x, const float* gamma, const float* beta, int32_t samples, int32_t rows,
+                             int32_t c, float eps, float* scale_shift, void* workspace, int64_t workspace_bytes,
+                             void* stream);
+int tc_conv_gn_eligible(const TcGemmParams* p, int32_t gn_rows);
+int tc_conv_gn_bf16(const TcGemmParams* p, const float* scale_shift, int32_t gn_rows, int32_t silu, void* stream);
 
 /* LayerNorm over the last axis of [rows, C] (attention.py:225-227), eps 1e-5, affine. */
 int tc_layernorm(const tc_bf16* x, tc_bf16* y, const float* gamma, const float* beta,

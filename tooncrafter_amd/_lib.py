@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libtooncrafter_hip.so")
 
-TC_ABI_VERSION = 9
+TC_ABI_VERSION = 10
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_GEGLU = 0, 1, 2, 3
 GATHER_LINEAR, GATHER_CONV3x3, GATHER_CONVT3 = 0, 1, 2
 
@@ -122,6 +122,10 @@ SYMBOLS = {
     "tc_gemm_gn_rows": (C.c_int, [C.POINTER(TcGemmParams)]),
     "tc_groupnorm_part": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "tc_groupnorm_scale_shift": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                           C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "tc_conv_gn_eligible": (C.c_int, [C.POINTER(TcGemmParams), C.c_int32]),
+    "tc_conv_gn_bf16": (C.c_int, [C.POINTER(TcGemmParams), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "tc_ff_geglu_fused_eligible": (C.c_int, [C.POINTER(TcFfParams)]),
     "tc_ff_geglu_fused": (C.c_int, [C.POINTER(TcFfParams), C.c_void_p]),
     "tc_temporal_attn_fused_eligible": (C.c_int, [C.POINTER(TcTbParams)]),

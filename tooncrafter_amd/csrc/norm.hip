@@ -157,6 +157,46 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   }
 }
 
+// ABI 10 (tc_groupnorm_scale_shift): the statistics as what a CONSUMER applies -- part [samples][nchunks][32][2] ->
+// ss [samples][2][c]: scale[ch] = rstd(group) * gamma[ch], shift[ch] = beta[ch] - mean(group) * scale[ch] (gn_apply's
+// prologue, once per tensor instead of once per block).  One block per sample: its four waves reduce eight groups each over
+// the chunks (fp64, fixed order, as gn_finalize), then all threads walk the channels.
+__global__ __launch_bounds__(256) void gn_finalize_ss_kernel(const float* __restrict__ part, float* __restrict__ ss,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             int rows, int c, int nchunks, float eps) {
+  __shared__ float st[32][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sample = blockIdx.x;
+  const int cpg = c / 32;
+  for (int g = wave * 8; g < wave * 8 + 8; ++g) {
+    const float* pp = part + ((int64_t)sample * nchunks * 32 + g) * 2;
+    double a = 0.0, b = 0.0;
+    for (int k = lane; k < nchunks; k += 64) {
+      const float2 v = *reinterpret_cast<const float2*>(pp + (int64_t)k * 64);
+      a += v.x;
+      b += v.y;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
+    if (lane == 0) {
+      const double cnt = (double)rows * cpg;
+      const double mean = a / cnt;
+      double var = b / cnt - mean * mean;
+      if (var < 0.0) var = 0.0;
+      st[g][0] = (float)mean;
+      st[g][1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+  }
+  __syncthreads();
+  float* o = ss + (int64_t)sample * 2 * c;
+  for (int ch = tid; ch < c; ch += 256) {
+    const int g = ch / cpg;
+    const float a = st[g][1] * gamma[ch];
+    o[ch] = a;
+    o[c + ch] = beta[ch] - st[g][0] * a;
+  }
+}
+
 // ABI 9: (mean, rstd) from a PRODUCER's partial sums (TcGemmParams.gn_part: per block of `prows` rows and per channel
 // the sum and the sum of squares of the values it stored): part [blocks][2][c] -> stats [samples][32][2].  One 256-thread
 // block per (sample, group): thread t takes row blocks t, t + 256, ... and walks the group's cpg contiguous channels
@@ -591,6 +631,27 @@ extern "C" int tc_groupnorm(const tc_bf16* x, tc_bf16* y, const float* gamma, co
                                reinterpret_cast<bf16_t*>(y), gamma, beta, stats, rows, c, cr);
   else hipLaunchKernelGGL(gn_apply_kernel<false>, grid, block, 0, s, reinterpret_cast<const bf16_t*>(x),
                           reinterpret_cast<bf16_t*>(y), gamma, beta, stats, rows, c, cr);
+  TC_LAUNCH_CHECK();
+  return TC_OK;
+}
+
+// ABI 10: GroupNorm's statistics pass alone, delivered as the per-(sample, channel) affine map its consumer applies
+// (tc_conv_gn_bf16 normalises its A operand with it: the apply pass and the normalised tensor disappear)
+extern "C" int tc_groupnorm_scale_shift(const tc_bf16* x, const float* gamma, const float* beta, int32_t samples, int32_t rows,
+                                        int32_t c, float eps, float* scale_shift, void* workspace, int64_t workspace_bytes,
+                                        void* stream) {
+  if (!x || !gamma || !beta || !scale_shift || !workspace || samples <= 0 || rows <= 0 || c <= 0) return TC_EINVAL;
+  if ((c % 32) != 0 || (c % 8) != 0 || c > GN_MAX_SLOTS * GN_THREADS * 8 || c > 4096 || samples > 65535) return TC_ESHAPE;
+  if (!tc_aligned16(x) || !tc_aligned16(scale_shift)) return TC_EALIGN;
+  if (workspace_bytes < tc_groupnorm_workspace(samples, rows, c)) return TC_EWORKSPACE;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int nch, cr;
+  gn_chunking(samples, rows, &nch, &cr);
+  float* part = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nch, samples), dim3(GN_THREADS), 0, s, reinterpret_cast<const bf16_t*>(x), part, rows, c,
+                     nch, cr);
+  TC_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gn_finalize_ss_kernel, dim3(samples), dim3(256), 0, s, part, scale_shift, gamma, beta, rows, c, nch, eps);
   TC_LAUNCH_CHECK();
   return TC_OK;
 }

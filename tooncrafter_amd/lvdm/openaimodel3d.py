@@ -105,12 +105,14 @@ class TemporalConvBlock(PackedModule):
         pk = self.pk
         y = act.rows
         geom = dict(kind="t3", frames=act.frames, t_len=act.t, cin=act.c, h_out=act.h, w_out=act.w)
+        # GroupNorm + SiLU + convolution as ONE operator (ops.gn_conv): two launches as before, or -- TC_GN_FUSE=1, ABI 10 -- a
+        # statistics pass and a convolution that normalises its own operand
+        gn = dict(samples=act.b, rows=act.t * act.hw, eps=1e-5, silu=True, conv=geom)
         for i in range(1, 5):
-            y = ops.groupnorm(y, pk[f"g{i}"], pk[f"b{i}"], samples=act.b, rows=act.t * act.hw, eps=1e-5, silu=True, part=part)
             if i < 4:
-                y, part = ops.gemm(y, pk[f"w{i}"], pk[f"cb{i}"], conv=geom, gn_stats=True)
+                y, part = ops.gn_conv(y, pk[f"g{i}"], pk[f"b{i}"], pk[f"w{i}"], pk[f"cb{i}"], part=part, gn_stats=True, **gn)
             else:
-                y = ops.gemm(y, pk[f"w{i}"], pk[f"cb{i}"], conv=geom, residual=act.rows)
+                y = ops.gn_conv(y, pk[f"g{i}"], pk[f"b{i}"], pk[f"w{i}"], pk[f"cb{i}"], part=part, residual=act.rows, **gn)
         return act.like(y)
 
 
@@ -152,16 +154,15 @@ class ResBlock(TimestepBlock, PackedModule):
         pk = self.pk
         off, width = self.emb_slice
         geom1, _, _ = _conv_geom(act, ceil_to(act.c, 64))
-        h = ops.groupnorm(act.rows, pk["g1"], pk["b1"], samples=act.frames, rows=act.hw, eps=1e-5, silu=True)
+        gn = dict(samples=act.frames, rows=act.hw, eps=1e-5, silu=True)
         # both convolutions feed a GroupNorm (out_layers' / the temporal block's first): they emit its statistics (ABI 9)
-        h, part = ops.gemm(h, pk["w1"], pk["cb1"], conv=geom1, row_bias=emb_all[:, off:off + width],
-                           row_div=act.t * act.hw, gn_stats=True)
-        h = ops.groupnorm(h, pk["g2"], pk["b2"], samples=act.frames, rows=act.hw, eps=1e-5, silu=True, part=part)
+        h, part = ops.gn_conv(act.rows, pk["g1"], pk["b1"], pk["w1"], pk["cb1"], conv=geom1, row_bias=emb_all[:, off:off + width],
+                              row_div=act.t * act.hw, gn_stats=True, **gn)
         skip = act.rows if "ws" not in pk else ops.gemm(act.rows, pk["ws"], pk["bs"])
         geom2, _, _ = _conv_geom(act, self.out_channels)
         if not self.use_temporal_conv:
-            return act.like(ops.gemm(h, pk["w2"], pk["cb2"], conv=geom2, residual=skip))
-        h, part = ops.gemm(h, pk["w2"], pk["cb2"], conv=geom2, residual=skip, gn_stats=True)
+            return act.like(ops.gn_conv(h, pk["g2"], pk["b2"], pk["w2"], pk["cb2"], conv=geom2, part=part, residual=skip, **gn))
+        h, part = ops.gn_conv(h, pk["g2"], pk["b2"], pk["w2"], pk["cb2"], conv=geom2, part=part, residual=skip, gn_stats=True, **gn)
         return self.temopral_conv(act.like(h), part)
 
 
