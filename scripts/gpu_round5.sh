@@ -3,6 +3,8 @@
 #   unver   : the GATED tests of kernels written without a GPU (conv_halo.hip) -- run FIRST, alone, short timeout
 #   halo    : kernel-level A/B of TC_CONV_HALO on the UNet's convolution shapes
 #   haloclip: clip-level A/B (alternating) of TC_CONV_HALO=1 against the default routing
+#   fuseunet: the full-size / tiny model parity tests with TC_GN_FUSE=1 TC_CONV_HALO=1 (GroupNorm inside the convolutions)
+#   fuseclip: clip-level A/B of (halo, fuse) = (0,0) (1,1) (0,0) (1,1) (1,0)
 #   gn      : GroupNorm operator timings on the UNet's shapes (the SiLU change of round 4's last session was never timed)
 #   all / smoke / bench / benchq / prof : as in scripts/gpu_round4.sh
 set -u
@@ -17,6 +19,8 @@ for s in "$@"; do
     halo)    timeout 300 python scripts/conv_halo_bench.py > $OUT/conv_halo_bench.txt 2>&1 ;;
     haloclip) (for v in 0 1 0 1; do echo "== TC_CONV_HALO=$v"; TC_CONV_HALO=$v timeout 300 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['stage_ms_per_clip'])"; done) > $OUT/conv_halo_clip_ab.txt 2>&1 ;;
     gn)      timeout 300 python scripts/norm_bench.py > $OUT/norm_bench.txt 2>&1 ;;
+    fuseunet) TC_GN_FUSE=1 TC_CONV_HALO=1 timeout 600 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_models.py -m gpu -x -q -p no:cacheprovider > $OUT/pytest_fused_unet.log 2>&1 ;;
+    fuseclip) (for v in "0 0" "1 1" "0 0" "1 1" "1 0"; do set -- $v; echo "== TC_CONV_HALO=$1 TC_GN_FUSE=$2"; TC_CONV_HALO=$1 TC_GN_FUSE=$2 timeout 300 python bench.py --steps 4 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['stage_ms_per_clip'], 'gemm frac', d['roofline']['frac'], 'gn ms', d['roofline_hbm']['ms_per_unet_fwd_b2'])"; done) > $OUT/fuse_clip_ab.txt 2>&1 ;;
     all)     timeout 900 python -m pytest tests -m gpu -x -q -p no:cacheprovider > $OUT/pytest_all.log 2>&1 ;;
     smoke)   timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1 ;;
     bench)   timeout 900 python bench.py --steps 10 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err ;;
