@@ -514,7 +514,7 @@ class HipOps:
         if self.gn_conv_eligible(x, w, conv, rows):
             self.gn_fuse_calls["fused"] += 1
             ss = self.groupnorm_scale_shift(x, gamma, beta, samples=samples, rows=rows, eps=eps)
-            return HipOps.gemm(self, x, w, bias, conv=conv, _gn=(ss, rows, silu), **kw)
+            return self.gemm(x, w, bias, conv=conv, _gn=(ss, rows, silu), **kw)
         self.gn_fuse_calls["separate"] += 1
         h = self.groupnorm(x, gamma, beta, samples=samples, rows=rows, eps=eps, silu=silu, part=part)
         return self.gemm(h, w, bias, conv=conv, **kw)
