@@ -21,17 +21,26 @@ def _hipcc():
     return None
 
 
-@pytest.fixture(scope="module")
-def norm_asm(tmp_path_factory):
+def _asm(tmp_path_factory, name):
     hipcc = _hipcc()
     if hipcc is None:
         pytest.skip("hipcc not on this host")
-    out = tmp_path_factory.mktemp("isa") / "norm.s"
+    out = tmp_path_factory.mktemp("isa") / (name + ".s")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", f"-I{ROOT}/include", f"-I{CSRC}",
-           "-S", "--cuda-device-only", os.path.join(CSRC, "norm.hip"), "-o", str(out)]
+           "-S", "--cuda-device-only", os.path.join(CSRC, name + ".hip"), "-o", str(out)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     return out.read_text()
+
+
+@pytest.fixture(scope="module")
+def norm_asm(tmp_path_factory):
+    return _asm(tmp_path_factory, "norm")
+
+
+@pytest.fixture(scope="module")
+def halo_asm(tmp_path_factory):
+    return _asm(tmp_path_factory, "conv_halo")
 
 
 def _kernels(asm):
@@ -65,3 +74,24 @@ def test_groupnorm_silu_is_the_reciprocal_form(norm_asm):
 def test_norm_kernels_do_not_spill(norm_asm):
     sizes = re.findall(r"^; ScratchSize: (\d+)", norm_asm, re.M)
     assert sizes and all(int(s) == 0 for s in sizes), sizes
+
+
+def test_conv_halo_kernels_fit_their_occupancy(halo_asm):
+    """csrc/conv_halo.hip, twelve instances (3x3 | temporal) x (160-row | tall | K split) x (plain | GroupNorm prologue): no
+    scratch, at most 256 VGPRs (two waves per SIMD), and the LDS the design counts on -- two 160-row blocks per CU
+    (<= 80 KiB each), one tall / K-split block (<= 160 KiB)."""
+    ks = _kernels(halo_asm)
+    assert len([n for n in ks if "conv_halo_kernel" in n]) == 12
+    # per-kernel resource comments follow each body in the listing, in order
+    names = re.findall(r"^(_Z\w*conv_halo_kernel\w*):", halo_asm, re.M)
+    vgpr = [int(v) for v in re.findall(r"^; NumVgprs: (\d+)", halo_asm, re.M)]
+    scratch = [int(v) for v in re.findall(r"^; ScratchSize: (\d+)", halo_asm, re.M)]
+    lds = [int(v) for v in re.findall(r"^; LDSByteSize: (\d+)", halo_asm, re.M)]
+    assert len(names) == len(vgpr) == len(scratch) == len(lds) == 12
+    for nm, v, sc, l in zip(names, vgpr, scratch, lds):
+        assert sc == 0 and v <= 256, (nm, v, sc)
+        small = "ELi2ELi1E" in nm                       # <GATHER, WM = 2, KS = 1, GN>
+        assert l <= (80 if small else 160) * 1024, (nm, l)
+        # the inline-asm DMA keeps the compiler from guarding fragment reads with vmcnt(0): the only full waits are ours
+        body = ks[nm]
+        assert body.count("buffer_load_dwordx4") >= 5 and "v_mfma_f32_16x16x32_bf16" in body
