@@ -89,3 +89,64 @@ def test_gn_conv_equals_groupnorm_then_convolution(kind):
     y = (x.float().reshape(gn["samples"], gn["rows"], c) * ss[:, 0][:, None] + ss[:, 1][:, None]).reshape(m, c)
     ref = plain.groupnorm(x, gamma, beta, eps=1e-5, silu=False, **gn).float()
     assert float((y - ref).abs().max()) < 3e-2 * float(ref.abs().max())
+
+
+def test_library_eligibility_rule_equals_the_emulation_rule():
+    """tc_conv_gn_eligible is host logic: callable without a GPU.  The emulation's restatement (EmuOps.gn_conv_eligible), which
+    the module-level tests above rely on, must agree with it on every shape class of the UNet and on the near misses."""
+    import ctypes as C
+
+    from tooncrafter_amd import _lib
+    from tooncrafter_amd._lib import GATHER_CONV3x3, GATHER_CONVT3, TcGemmParams
+    lib = _lib.load()
+    emu = EmuOps(gn_fuse=True)
+    cases = []
+    for frames in (16, 32, 4):
+        for h, w in ((40, 64), (20, 32), (10, 16), (5, 8), (8, 8), (30, 48), (10, 24)):
+            for cin, n in ((320, 320), (640, 320), (64, 160), (320, 128), (96, 160)):
+                for kind in ("3x3", "t3"):
+                    for rows in (h * w, 16 * h * w, frames * h * w, 7):
+                        cases.append((kind, frames, h, w, cin, n, rows))
+    agree_yes = 0
+    for kind, frames, h, w, cin, n, rows in cases:
+        taps = 9 if kind == "3x3" else 3
+        p = TcGemmParams()
+        p.gather = GATHER_CONV3x3 if kind == "3x3" else GATHER_CONVT3
+        p.cin, p.frames, p.t_len, p.h_out, p.w_out, p.h_in, p.w_in = cin, frames, 16 if kind == "t3" else 1, h, w, h, w
+        p.stride, p.upsample, p.pad = 1, 0, 1
+        p.m, p.n, p.k = frames * h * w, n, taps * cin
+        p.lda, p.ldw, p.ldc, p.ldr, p.ldrb, p.row_div, p.alpha, p.out_scale, p.batch = cin, taps * cin, n, n, n, 1, 1.0, 1.0, 1
+        got = bool(lib.tc_conv_gn_eligible(C.byref(p), rows))
+        conv = dict(kind=kind, frames=frames, cin=cin, h_in=h, w_in=w, h_out=h, w_out=w, stride=1, upsample=False, t_len=16)
+        x = torch.empty((1, cin), dtype=torch.bfloat16)
+        wt = torch.empty((n, taps * cin), dtype=torch.bfloat16)
+        want = emu.gn_conv_eligible(x, wt, conv, rows)
+        assert got == want, (kind, frames, h, w, cin, n, rows, got, want)
+        agree_yes += got
+    assert agree_yes >= 40           # the UNet's levels 0-2, per-frame and clip-wide statistics, both convolution kinds
+
+
+def test_conv_gn_entry_refuses_bad_calls_before_it_launches():
+    """Error paths of tc_conv_gn_bf16 / tc_groupnorm_scale_shift return before any launch: checkable without a GPU."""
+    import ctypes as C
+
+    from tooncrafter_amd import _lib
+    from tooncrafter_amd._lib import GATHER_CONV3x3, TcGemmParams
+    lib = _lib.load()
+    EINVAL, EALIGN, ESHAPE, EWORKSPACE = -1, -2, -3, -4          # include/tooncrafter_hip.h (TcStatus); _lib.ERRORS
+    buf = (C.c_char * 4096)()
+    base = (C.addressof(buf) + 63) & ~63                     # a 64-byte aligned host address: never dereferenced on these paths
+    p = TcGemmParams()
+    p.gather, p.cin, p.frames, p.t_len, p.h_out, p.w_out, p.h_in, p.w_in = GATHER_CONV3x3, 64, 2, 1, 8, 8, 8, 8
+    p.stride, p.upsample, p.pad = 1, 0, 1
+    p.m, p.n, p.k = 2 * 64, 160, 9 * 64
+    p.lda, p.ldw, p.ldc, p.ldr, p.ldrb, p.row_div, p.alpha, p.out_scale, p.batch = 64, 9 * 64, 160, 160, 160, 1, 1.0, 1.0, 1
+    p.a = p.w = p.c = base
+    assert lib.tc_conv_gn_bf16(C.byref(p), None, 64, 1, None) == EINVAL              # no table
+    assert lib.tc_conv_gn_bf16(C.byref(p), base + 4, 64, 1, None) == EALIGN          # misaligned table
+    assert lib.tc_conv_gn_bf16(C.byref(p), base, 64, 1, None) == ESHAPE              # 8 x 8 images: no patches
+    p.a = 0
+    assert lib.tc_conv_gn_bf16(C.byref(p), base, 64, 1, None) == EINVAL
+    assert lib.tc_groupnorm_scale_shift(None, base, base, 2, 64, 64, 1e-5, base, base, 1 << 20, None) == EINVAL
+    assert lib.tc_groupnorm_scale_shift(base, base, base, 2, 64, 48, 1e-5, base, base, 1 << 20, None) == ESHAPE   # C % 32
+    assert lib.tc_groupnorm_scale_shift(base, base, base, 2, 64, 64, 1e-5, base, base, 16, None) == EWORKSPACE

@@ -465,9 +465,13 @@ int tc_conv_halo_try(const TcGemmParams& p, int batch, hipStream_t s, bool dry) 
 }
 
 // ---- ABI 10: the convolution of GroupNorm(+SiLU)(x), statistics as a (scale, shift) table (tc_groupnorm_scale_shift)
-static int conv_gn_check(const TcGemmParams& p) {
-  if (!p.a || !p.w || !p.c || p.m <= 0 || p.n <= 0 || p.k <= 0) return TC_EINVAL;
-  if (!tc_aligned16(p.a) || !tc_aligned16(p.w) || !tc_aligned16(p.c)) return TC_EALIGN;
+// (pointers = false: the eligibility question is asked with a geometry-only struct)
+static int conv_gn_check(const TcGemmParams& p, bool pointers) {
+  if (p.m <= 0 || p.n <= 0 || p.k <= 0) return TC_EINVAL;
+  if (pointers) {
+    if (!p.a || !p.w || !p.c) return TC_EINVAL;
+    if (!tc_aligned16(p.a) || !tc_aligned16(p.w) || !tc_aligned16(p.c)) return TC_EALIGN;
+  }
   if (p.residual && !tc_aligned16(p.residual)) return TC_EALIGN;
   if ((p.k & 7) || (p.lda & 7) || (p.ldw & 7) || (p.n & 7)) return TC_EALIGN;
   if (p.out_f32 ? (p.ldc & 3) : (p.ldc & 7)) return TC_EALIGN;
@@ -486,7 +490,7 @@ static int conv_gn_check(const TcGemmParams& p) {
 }
 
 extern "C" int tc_conv_gn_eligible(const TcGemmParams* pp, int32_t gn_rows) {
-  if (!pp || conv_gn_check(*pp) != TC_OK) return 0;
+  if (!pp || conv_gn_check(*pp, false) != TC_OK) return 0;
   static const float dummy = 0.f;
   return conv_halo_launch(*pp, pp->batch > 0 ? pp->batch : 1, nullptr, true, ChGn{&dummy, gn_rows, 1});
 }
@@ -494,7 +498,7 @@ extern "C" int tc_conv_gn_eligible(const TcGemmParams* pp, int32_t gn_rows) {
 extern "C" int tc_conv_gn_bf16(const TcGemmParams* pp, const float* scale_shift, int32_t gn_rows, int32_t silu, void* stream) {
   if (!pp || !scale_shift) return TC_EINVAL;
   if (!tc_aligned16(scale_shift)) return TC_EALIGN;
-  const int rc = conv_gn_check(*pp);
+  const int rc = conv_gn_check(*pp, true);
   if (rc != TC_OK) return rc;
   if (!conv_halo_launch(*pp, pp->batch > 0 ? pp->batch : 1, reinterpret_cast<hipStream_t>(stream), false,
                         ChGn{scale_shift, gn_rows, silu ? 1 : 0})) return TC_ESHAPE;
