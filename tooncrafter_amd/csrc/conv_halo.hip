@@ -460,6 +460,12 @@ int tc_conv_halo_try(const TcGemmParams& p, int batch, hipStream_t s, bool dry) 
   const int mode = conv_halo_mode();
   if (mode == 0) return 0;
   if (p.gather != TC_GATHER_CONV3x3 && p.gather != TC_GATHER_CONVT3) return 0;
+  if (mode == 1) {
+    // per-kind switches for the routing once the A/B of scripts/conv_halo_bench.py is in: TC_CONV_HALO_3X3=0 / TC_CONV_HALO_T3=0
+    // keep that kind on the implicit GEMM (strict mode ignores them)
+    const char* e = getenv(p.gather == TC_GATHER_CONV3x3 ? "TC_CONV_HALO_3X3" : "TC_CONV_HALO_T3");
+    if (e && e[0] == '0') return 0;
+  }
   const int r = conv_halo_launch(p, batch, s, dry, ChGn{nullptr, 0, 0});
   return r ? 1 : (mode == 2 ? -1 : 0);
 }
