@@ -150,3 +150,24 @@ def test_conv_gn_entry_refuses_bad_calls_before_it_launches():
     assert lib.tc_groupnorm_scale_shift(None, base, base, 2, 64, 64, 1e-5, base, base, 1 << 20, None) == EINVAL
     assert lib.tc_groupnorm_scale_shift(base, base, base, 2, 64, 48, 1e-5, base, base, 1 << 20, None) == ESHAPE   # C % 32
     assert lib.tc_groupnorm_scale_shift(base, base, base, 2, 64, 64, 1e-5, base, base, 16, None) == EWORKSPACE
+
+
+def test_strict_halo_mode_refuses_a_convolution_it_cannot_take(monkeypatch):
+    """TC_CONV_HALO=2 (the parity tests' mode): tc_gemm_bf16 fails with TC_ESHAPE -- before any launch, so checkable here --
+    instead of silently falling back to the implicit GEMM for a convolution the tap-reuse kernel cannot take."""
+    import ctypes as C
+
+    from tooncrafter_amd import _lib
+    from tooncrafter_amd._lib import GATHER_CONV3x3, TcGemmParams
+    lib = _lib.load()
+    buf = (C.c_char * 4096)()
+    base = (C.addressof(buf) + 63) & ~63
+    p = TcGemmParams()
+    p.gather, p.cin, p.frames, p.t_len, p.h_out, p.w_out, p.h_in, p.w_in = GATHER_CONV3x3, 64, 2, 1, 17, 23, 17, 23
+    p.stride, p.upsample, p.pad = 1, 0, 1
+    p.m, p.n, p.k = 2 * 17 * 23, 160, 9 * 64
+    p.lda, p.ldw, p.ldc, p.ldr, p.ldrb, p.row_div, p.alpha, p.out_scale, p.batch = 64, 9 * 64, 160, 160, 160, 1, 1.0, 1.0, 1
+    p.a = p.w = p.c = base
+    monkeypatch.setenv("TC_CONV_HALO", "2")
+    assert lib.tc_gemm_bf16(C.byref(p), None) == -3                 # TC_ESHAPE: 17 x 23 images do not tile into patches
+    assert lib.tc_gemm_gn_rows(C.byref(p)) == 0                     # and such a problem emits no producer statistics either
