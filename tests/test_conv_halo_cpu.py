@@ -96,9 +96,13 @@ class HaloKernelModel:
             mine = []
             for i in range(7):
                 v = tid + self.threads * i
-                pix, seg = v >> 3, v & 7
-                hy, hx = divmod(pix, CH_HX)
-                ok = pix < self.npix
+                q, seg = v >> 3, v & 7
+                if self.g == CONV3x3:
+                    hy, hx = divmod(q, CH_HX)
+                else:
+                    hx, hy = divmod(q, self.PY)             # pixel-fastest: a frame's pixels are adjacent source rows
+                pix = hy * CH_HX + hx if q < self.npix else self.npix
+                ok = q < self.npix
                 if self.g == CONV3x3:
                     iy, ix = Y0 + hy - 1, X0 + hx - 1
                     ok = ok and 0 <= iy < self.h and 0 <= ix < self.wd

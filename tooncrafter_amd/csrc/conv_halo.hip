@@ -144,9 +144,15 @@ __global__ __launch_bounds__(128 * WM * KS, (WM == 2 && KS == 1) ? 2 : 1) void c
 #pragma unroll
   for (int i = 0; i < CH_NV; ++i) {
     const int v = tid + G::THREADS * i;
-    const int pix = v >> 3, seg = v & 7;
-    const int hy = pix / CH_HX, hx = pix - hy * CH_HX;
-    bool ok = pix < G::NPIX;
+    const int q = v >> 3, seg = v & 7;
+    // thread -> halo pixel: consecutive lane octets walk the direction in which SOURCE rows are adjacent -- along x for the
+    // 3x3 patch (q = 18 hy + hx), along the PIXELS of a frame for the temporal one (q = PY hx + hy: a frame's PY pixels are
+    // PY consecutive rows; its frames are H * W rows apart).  The LDS image is hp = 18 hy + hx either way.
+    int hy, hx;
+    if (GATHER == TC_GATHER_CONV3x3) { hy = q / CH_HX; hx = q - hy * CH_HX; }
+    else { hx = q / PY; hy = q - hx * PY; }
+    const int pix = q < G::NPIX ? hy * CH_HX + hx : G::NPIX;
+    bool ok = q < G::NPIX;
     int64_t src;
     if (GATHER == TC_GATHER_CONV3x3) {
       const int iy = Y0 + hy - 1, ix = X0 + hx - 1;
