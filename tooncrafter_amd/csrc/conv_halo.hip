@@ -30,14 +30,18 @@
 // rounding of the accumulators, not bit for bit.
 #include "gemm_persist.h"
 
+#include "conv_halo_index.h"
+
 #include <stdlib.h>
 
 namespace {
 
-constexpr int CH_BN = 160, CH_WT = 80, CH_NT = 5;
-constexpr int CH_HX = 18;                                  // halo patch width (16 + 2) for both geometries
-constexpr int CH_W_STAGE = CH_BN * TC_BK * 2;              // 20 KiB
-constexpr int CH_NV = 7;                                   // halo vectors per thread and chunk: ceil(216 * 8 / 256) = ceil(396 * 8 / 512)
+// every address formula of the kernel lives in conv_halo_index.h (namespace chx), shared with the host-side check
+constexpr int CH_BN = chx::BN, CH_WT = chx::WT, CH_NT = chx::NT;
+constexpr int CH_HX = chx::HX;                             // halo patch width (16 + 2) for both geometries
+constexpr int CH_W_STAGE = chx::W_STAGE;                   // 20 KiB
+constexpr int CH_NV = chx::NV;                             // halo vectors per thread and chunk: ceil(216 * 8 / 256) = ceil(396 * 8 / 512)
+static_assert(chx::GATHER_3x3 == TC_GATHER_CONV3x3 && chx::GATHER_T3 == TC_GATHER_CONVT3 && chx::BK == TC_BK && chx::OOB == TC_OOB, "conv_halo_index.h");
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 // WM = waves along M: 2 = the 160-row patch (PY = 10 patch rows, 4 waves, two blocks per CU); 4 = a TALL 320-row patch
@@ -45,15 +49,7 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 // chunk and NINE K-steps -- so the W tile is what a K-step pays for, and a tall block requests it once for twice the rows:
 // 25.6 KiB per 320 x 160 x 64 step, 9.8 TB/s chip-wide at the MFMA roof (the 160-row patch: 18; the implicit GEMM: 31).
 template <int GATHER, int WM>
-struct ChGeo {                                             // 3x3: y = image row, x = pixel; temporal: y = pixel, x = frame
-  static constexpr int TAPS = GATHER == TC_GATHER_CONV3x3 ? 9 : 3;
-  static constexpr int PY = 5 * WM;                        // patch rows: 10 | 20
-  static constexpr int HY = GATHER == TC_GATHER_CONV3x3 ? PY + 2 : PY;
-  static constexpr int NPIX = HY * CH_HX;                  // 216 | 180 | 396 | 360
-  static constexpr int THREADS = 128 * WM;
-  static constexpr int A_BYTES = (NPIX * 128 + 1023) / 1024 * 1024;       // 27 | 23 | 50 | 45 KiB
-  static_assert(NPIX * 8 <= CH_NV * THREADS, "halo vectors per thread");
-};
+using ChGeo = chx::Shape<GATHER, WM>;                      // TAPS, PY, HY, NPIX, THREADS, A_BYTES, RSTEP, RB, PIECE
 
 // KS = 2 (TC_CONV_HALO_KSPLIT, WM = 2 only): the K loop split over TWO 4-wave groups inside one 8-wave block -- for the
 // launches whose patches do not fill the chip (level 2: 256 tiles on 256 CUs = one 4-wave block per CU, one MFMA wave per
@@ -105,32 +101,14 @@ __global__ __launch_bounds__(128 * WM * KS, (WM == 2 && KS == 1) ? 2 : 1) void c
   // ---- block -> patch
   const int hw = p.h_out * p.w_out;
   const int tiles_n = p.n / CH_BN;
-  int per_img, tiles_m;                                    // patches per frame (3x3) | per clip (temporal)
-  if (GATHER == TC_GATHER_CONV3x3) { per_img = (p.h_out / PY) * (p.w_out / 16); tiles_m = p.frames * per_img; }
-  else { per_img = hw / PY; tiles_m = (p.frames / 16) * per_img; }
+  const int tiles_m = chx::tiles_m<GATHER, WM>(p.frames, p.h_out, p.w_out);
   int tile_m, tile_n;
   tc_tile_of_block(blockIdx.x, tiles_m, tiles_n, order, tile_m, tile_n);
   if (tile_m >= tiles_m) return;
-  const int img = tile_m / per_img, pin = tile_m - img * per_img;
-  // output row of patch position (y, x): m = m00 + y * ys + x * xs
-  int64_t m00;
-  int ys, xs, Y0 = 0, X0 = 0;
-  if (GATHER == TC_GATHER_CONV3x3) {
-    const int tpx = p.w_out / 16;
-    const int ty0 = pin / tpx;
-    Y0 = ty0 * PY;
-    X0 = (pin - ty0 * tpx) * 16;
-    m00 = ((int64_t)img * p.h_out + Y0) * p.w_out + X0;
-    ys = p.w_out;
-    xs = 1;
-  } else {
-    m00 = (int64_t)img * 16 * hw + pin * PY;
-    ys = 1;
-    xs = hw;
-  }
-  // lowest source row the patch can touch: the SRD of A starts there (31-bit offsets span one patch)
-  int64_t row_lo = GATHER == TC_GATHER_CONV3x3 ? m00 - p.w_out - 1 : m00;
-  if (row_lo < 0) row_lo = 0;
+  const chx::Patch pt = chx::patch_of<GATHER, WM>(tile_m, p.h_out, p.w_out);
+  const int img = pt.img;
+  const int64_t m00 = pt.m00, row_lo = pt.row_lo;            // first output row; lowest source row (the SRD of A starts there)
+  const int ys = pt.ys, xs = pt.xs;                          // output row of patch position (y, x): m00 + y ys + x xs
 
   const int64_t bz = blockIdx.z;
   const tc_rsrc_t a_rsrc = tc_a_rsrc(p, bz, row_lo);
@@ -143,27 +121,9 @@ __global__ __launch_bounds__(128 * WM * KS, (WM == 2 && KS == 1) ? 2 : 1) void c
   int hv_lds[CH_NV];                                       // -1: no such pixel
 #pragma unroll
   for (int i = 0; i < CH_NV; ++i) {
-    const int v = tid + G::THREADS * i;
-    const int q = v >> 3, seg = v & 7;
-    // thread -> halo pixel: consecutive lane octets walk the direction in which SOURCE rows are adjacent -- along x for the
-    // 3x3 patch (q = 18 hy + hx), along the PIXELS of a frame for the temporal one (q = PY hx + hy: a frame's PY pixels are
-    // PY consecutive rows; its frames are H * W rows apart).  The LDS image is hp = 18 hy + hx either way.
-    int hy, hx;
-    if (GATHER == TC_GATHER_CONV3x3) { hy = q / CH_HX; hx = q - hy * CH_HX; }
-    else { hx = q / PY; hy = q - hx * PY; }
-    const int pix = q < G::NPIX ? hy * CH_HX + hx : G::NPIX;
-    bool ok = q < G::NPIX;
-    int64_t src;
-    if (GATHER == TC_GATHER_CONV3x3) {
-      const int iy = Y0 + hy - 1, ix = X0 + hx - 1;
-      ok = ok && iy >= 0 && iy < p.h_in && ix >= 0 && ix < p.w_in;
-      src = ((int64_t)img * p.h_in + iy) * p.w_in + ix;
-    } else {
-      ok = ok && hx >= 1 && hx <= 16;
-      src = ((int64_t)img * 16 + (hx - 1)) * hw + pin * PY + hy;
-    }
-    hv_off[i] = ok ? (uint32_t)((src - row_lo) * p.lda * 2 + seg * 16) : TC_OOB;       // outside the image: zeros
-    hv_lds[i] = pix < G::NPIX ? pix * 128 + ((seg ^ (pix & 7)) << 4) : -1;
+    const chx::HaloVec hvv = chx::halo_vec<GATHER, WM>(pt, tid, i, p.h_in, p.w_in, p.lda);     // (h_in = h_out, w_in = w_out: host)
+    hv_off[i] = hvv.off;
+    hv_lds[i] = hvv.lds;
   }
   u32x4 hv[CH_NV];
   f32x4 g_sc[2], g_sh[2];                                  // GN: scale / shift of this thread's 8 channels of the chunk
@@ -212,9 +172,9 @@ __global__ __launch_bounds__(128 * WM * KS, (WM == 2 && KS == 1) ? 2 : 1) void c
   // ---- W tile requests: thread -> (row lrow + RSTEP i, 16-byte chunk), the swizzle on the SOURCE chunk (gemm16.hip).
   // The tall block's third pass covers rows 128..191 of a 160-row tile: waves 4..7 have no rows there and request nothing
   // (every wait of this loop is vmcnt(0): the waves need not issue equal numbers of requests)
-  constexpr int RSTEP = 16 * WM, RB = (CH_BN + RSTEP - 1) / RSTEP, PIECE = RSTEP * TC_BK * 2;      // 32 | 64 rows per pass, 5 | 3 passes
-  const int lrow = tid >> 3;
-  const int wchunk = (tid & 7) ^ ((lrow >> 1) & 7);
+  constexpr int RSTEP = G::RSTEP, RB = G::RB, PIECE = G::PIECE;      // 32 | 64 rows per pass, 5 | 3 passes
+  const int lrow = chx::w_lrow(tid);
+  const int wchunk = chx::w_chunk(tid);
   uint32_t b_voff[RB];
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
@@ -227,7 +187,7 @@ __global__ __launch_bounds__(128 * WM * KS, (WM == 2 && KS == 1) ? 2 : 1) void c
     const uint32_t soff = (uint32_t)k0 * 2u;
 #pragma unroll
     for (int i = 0; i < RB; ++i)
-      if (WM == 2 || i < RB - 1 || wave_u < 4) g8_dma16(w_srd, dst + i * PIECE, b_voff[i], soff);
+      if (chx::w_pass_live<WM>(i, wave_u)) g8_dma16(w_srd, dst + i * PIECE, b_voff[i], soff);
   };
 
   f32x4_t acc[CH_NT][CH_NT];
@@ -242,23 +202,19 @@ __global__ __launch_bounds__(128 * WM * KS, (WM == 2 && KS == 1) ? 2 : 1) void c
   int hp0[CH_NT], b_off[CH_NT];
 #pragma unroll
   for (int i = 0; i < CH_NT; ++i) {
-    hp0[i] = (wm * 5 + i) * CH_HX + frow;                  // halo pixel of (y = 5 wm + i, x = frow) for tap (0, 0)
-    b_off[i] = (wn * CH_WT + i * 16 + frow) * (TC_BK * 2);
+    hp0[i] = chx::frag_a_hp0(wm, i, frow);                 // halo pixel of (y = 5 wm + i, x = frow) for tap (0, 0)
+    b_off[i] = chx::frag_b_off(wn, i, frow);
   }
-  const int b_sw = ((wn * CH_WT + frow) >> 1) & 7;
 
   auto compute = [&](int stage, int shift) {
     const char* sb = sW + stage * CH_W_STAGE;
     int a_addr[CH_NT];
 #pragma unroll
-    for (int i = 0; i < CH_NT; ++i) {
-      const int hp = hp0[i] + shift;
-      a_addr[i] = (hp << 7) + ((fq ^ (hp & 7)) << 4);      // K-slice 0: segment fq; slice 1: segment 4 + fq = this ^ 64
-    }
+    for (int i = 0; i < CH_NT; ++i) a_addr[i] = chx::frag_a_addr(hp0[i], shift, fq);      // K-slice 0; slice 1 = this ^ 64
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[CH_NT], bf[CH_NT];
-      const int cb = ((ks * 4 + fq) ^ b_sw) << 4;
+      const int cb = chx::frag_b_chunk(wn, frow, fq, ks);
 #pragma unroll
       for (int i = 0; i < CH_NT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sA + (a_addr[i] ^ (ks << 6)));
 #pragma unroll
@@ -275,7 +231,7 @@ __global__ __launch_bounds__(128 * WM * KS, (WM == 2 && KS == 1) ? 2 : 1) void c
   const int nch = (p.cin / TC_BK) / KS;                    // chunks of this group (KS = 2: cin / 64 is even -- host)
   const int c0 = grp_u * nch;                              // its first chunk
   const int nk = G::TAPS * nch;
-  request_w(c0 * TC_BK, 0);
+  request_w(chx::w_k0(0, c0, p.cin), 0);
   load_halo(c0);
   transform_halo();
   store_halo();
@@ -289,9 +245,9 @@ __global__ __launch_bounds__(128 * WM * KS, (WM == 2 && KS == 1) ? 2 : 1) void c
     if (ntap == G::TAPS) { ntap = 0; nc = c + 1; nty = 0; ntx = 0; }
     const bool more = kb + 1 < nk;
     const bool refill = more && ntap == 0;                 // block-uniform: the next step opens a new channel chunk
-    if (more) request_w(ntap * p.cin + (c0 + nc) * TC_BK, st ^ 1);
+    if (more) request_w(chx::w_k0(ntap, c0 + nc, p.cin), st ^ 1);
     if (refill) load_halo(c0 + nc);
-    compute(st, GATHER == TC_GATHER_CONV3x3 ? ty * CH_HX + tx : tx);
+    compute(st, chx::tap_shift(GATHER, ty, tx));
     if (refill) transform_halo();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // own pieces of W(kb + 1) (and the halo vectors) have landed
     __syncthreads();                                       // every wave's fragment reads of this step are done
@@ -338,12 +294,11 @@ __global__ __launch_bounds__(128 * WM * KS, (WM == 2 && KS == 1) ? 2 : 1) void c
 #pragma unroll
       for (int r = 0; r < 4; ++r) slab[(fq * 4 + r) * CH_WT + j * 16 + frow] = acc[i][j][r];
     // the same wave reads back (LDS operations of one wave complete in order): 160 vectors over 64 lanes
-    const int64_t row_base = m00 + (int64_t)(wm * 5 + i) * ys;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       const int v = lane + 64 * q;
       const int lr = v / VPR, vc = v - lr * VPR;
-      const int m = (int)(row_base + (int64_t)lr * xs);
+      const int m = (int)chx::out_row(pt, wm, i, lr);
       const int n0 = col_w0 + vc * 8;
       if (v < 16 * VPR && m < p.m && n0 < p.n) {
         const f32x4 lo = *reinterpret_cast<const f32x4*>(slab + lr * CH_WT + vc * 8);
