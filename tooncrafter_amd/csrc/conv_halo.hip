@@ -128,10 +128,7 @@ __global__ __launch_bounds__(128 * WM * KS, (WM == 2 && KS == 1) ? 2 : 1) void c
   u32x4 hv[CH_NV];
   f32x4 g_sc[2], g_sh[2];                                  // GN: scale / shift of this thread's 8 channels of the chunk
   const float* gn_base = nullptr;
-  if (GN) {
-    const int64_t any_row = GATHER == TC_GATHER_CONV3x3 ? (int64_t)img * hw : (int64_t)img * 16 * hw;     // a row of the patch's sample
-    gn_base = gn.ss + (any_row / gn.rows) * 2 * p.cin + (tid & 7) * 8;
-  }
+  if (GN) gn_base = gn.ss + chx::gn_table_offset<GATHER>(pt, p.h_out, p.w_out, gn.rows, p.cin, tid);
   auto load_halo = [&](int chunk_idx) {
     const uint32_t soff = (uint32_t)chunk_idx * (TC_BK * 2);
 #pragma unroll
