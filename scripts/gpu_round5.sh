@@ -5,6 +5,7 @@
 #   haloclip: clip-level A/B (alternating) of TC_CONV_HALO=1 against the default routing
 #   fuseunet: the full-size / tiny model parity tests with TC_GN_FUSE=1 TC_CONV_HALO=1 (GroupNorm inside the convolutions)
 #   fuseclip: clip-level A/B of (halo, fuse) = (0,0) (1,1) (0,0) (1,1) (1,0)
+#   pmchalo : SQ / LDS / L2 counters of the level-0 3x3 convolution on gemm16 vs the halo kernel (three --pmc passes)
 #   gn      : GroupNorm operator timings on the UNet's shapes (the SiLU change of round 4's last session was never timed)
 #   all / smoke / bench / benchq / prof : as in scripts/gpu_round4.sh
 set -u
@@ -26,6 +27,7 @@ for s in "$@"; do
     bench)   timeout 900 python bench.py --steps 10 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err ;;
     benchq)  timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_quick.json 2> $OUT/bench_quick.err ;;
     prof)    (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/profclip -o prof -- python $REPO/bench.py --steps 1 --warmup 0 --ddim-steps 10 --no-cpu-baseline --no-roofline > $REPO/$OUT/prof.log 2>&1; python $REPO/scripts/prof_summary.py "$(find /tmp/profclip -name '*.db' | head -1)" 50 > $REPO/$OUT/prof_stats.txt 2>> $REPO/$OUT/prof.log) ;;
+    pmchalo) bash scripts/pmc_halo.sh > $OUT/pmc_halo.log 2>&1 ;;
     halodbg) (for a in "3x3" "t3" "3x3 2 20 32 128 160 tall" "3x3 2 10 16 256 160 ksplit" "3x3 2 20 32 128 160 gn"; do timeout 120 python scripts/conv_halo_debug.py $a; done) > $OUT/conv_halo_debug.txt 2>&1 ;;
     py:*)    timeout 600 python ${s#py:} > $OUT/$(basename ${s#py:} .py).txt 2>&1 ;;
     *) echo "unknown stage $s" ;;
