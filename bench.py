@@ -42,7 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from tooncrafter_amd import ops, synth  # noqa: E402
+from tooncrafter_amd import clip as clip_api, ops, synth  # noqa: E402
 
 UNET_CFG = dict(in_channels=8, out_channels=4, model_channels=320, attention_resolutions=[4, 2, 1],
                 num_res_blocks=2, channel_mult=[1, 2, 4, 4], dropout=0.1, num_head_channels=64,
@@ -137,13 +137,9 @@ def run_clip(model, sampler, inp, ddim_steps):
                                 cfg_img=None, mask=None, x0=None, fs=inp["fs"], timestep_spacing="uniform_trailing",
                                 guidance_rescale=0.7, x_T=inp["x_T"], unconditional_conditioning_img_nonetext=None)
     e1 = _mark()
-    video = model.decode_first_stage(samples, ref_context=inp["refs"])
-    e2 = _mark()
-    idx = [i for i in range(samples.shape[2]) if i not in (1, samples.shape[2] - 2)]
-    video2 = model.decode_first_stage(samples[:, :, idx].contiguous(), ref_context=inp["refs"])
-    mid = video2.shape[2] // 2
-    video[:, :, 7:9] = video2[:, :, mid - 1:mid + 1]          # splice the two middle frames (inference.py:268-270)
-    e3 = _mark()
+    mid_mark = []
+    video = clip_api.decode_spliced(model, samples, inp["refs"], marks=lambda: mid_mark.append(_mark()))
+    e2, e3 = mid_mark[0], _mark()
     STAGE_EVENTS.extend([("ddim_sampler", e0, e1), ("decode_16f", e1, e2), ("decode_14f_splice", e2, e3)])
     return video
 

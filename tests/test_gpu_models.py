@@ -363,7 +363,7 @@ def test_pipeline_vs_reference_image_guided_synthesis(hip, tiny_sd):
     from conftest import GOLDEN as GOLDEN_DIR
     sys.path.insert(0, GOLDEN_DIR)
     import pipeline_stubs as stubs
-    from tooncrafter_amd import pipeline
+    from tooncrafter_amd import clip as pipeline
     from tooncrafter_amd.lvdm import autoencoder as my_ae, ddim as my_ddim
     g = load_golden("pipeline_tiny.npz")
     model = _tiny_pipeline(tiny_sd)

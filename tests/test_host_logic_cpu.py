@@ -329,7 +329,7 @@ def test_pipeline_matches_reference_image_guided_synthesis(tiny_sd):
     import sys
     sys.path.insert(0, GOLDEN_DIR)
     import pipeline_stubs as stubs
-    from tooncrafter_amd import pipeline
+    from tooncrafter_amd import clip as pipeline
     from tooncrafter_amd.lvdm import autoencoder as my_ae, ddim as my_ddim
     from tooncrafter_amd.utils import instantiate_from_config
     g = load_golden("pipeline_tiny.npz")

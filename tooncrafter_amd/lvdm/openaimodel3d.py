@@ -337,13 +337,15 @@ class UNetModel(PackedModule):
         mc = self.model_channels
         ted = 4 * mc
         dev = timesteps.device
-        te = ops.timestep_embedding(timesteps if timesteps.dtype == torch.int64 else timesteps.to(torch.float32), mc, ceil_to(mc, 8))
+        def dense(v):          # a drop-in caller may hand over `t.expand(b)` or a strided view: the kernel reads [n] densely
+            return (v if v.dtype == torch.int64 else v.to(torch.float32)).contiguous()
+        te = ops.timestep_embedding(dense(timesteps), mc, ceil_to(mc, 8))
         hcat = torch.empty((b, 2 * ted if self.fs_condition else ted), dtype=torch.bfloat16, device=dev)
         ops.gemm(te, pk["te_w0"], pk["te_b0"], act=ACT_SILU, out=hcat[:, :ted])
         if self.fs_condition:
             if fs is None:
                 fs = torch.full((b,), self.default_fs, dtype=torch.long, device=dev)
-            fe = ops.timestep_embedding(fs if fs.dtype == torch.int64 else fs.to(torch.float32), mc, ceil_to(mc, 8))
+            fe = ops.timestep_embedding(dense(fs), mc, ceil_to(mc, 8))
             ops.gemm(fe, pk["fe_w0"], pk["fe_b0"], act=ACT_SILU, out=hcat[:, ted:])
         # emb_layers = SiLU -> Linear for all ResBlocks at once (openaimodel3d.py:168-174, 219)
         semb = ops.gemm(hcat, pk["e2_w"], pk["e2_b"], act=ACT_SILU)
