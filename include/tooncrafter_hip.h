@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TC_ABI_VERSION 10
+#define TC_ABI_VERSION 11
 
 enum {
   TC_OK = 0,
@@ -227,6 +227,23 @@ int tc_groupnorm(const tc_bf16* x, tc_bf16* y, const float* gamma, const float* 
 int tc_groupnorm_part(const tc_bf16* x, tc_bf16* y, const float* gamma, const float* beta, const float* part,
                       int32_t part_rows, int32_t samples, int32_t rows, int32_t c, float eps, int32_t silu,
                       void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ABI 11 -- the same operator as ONE launch that reads x once and writes y once (csrc/gn_coop.hip): the tensor is held in
+ * the chip's register files by a grid of co-resident blocks that meet per sample at an atomic counter; for the tensors
+ * whose (sample, channel-unit) slabs do not fit one block (UNet level 0, the clip-wide norms of levels 1 / 2: GroupNormSpecific
+ * and nn.GroupNorm + SiLU of lvdm/basics.py:76-87, openaimodel3d.py:152-154,176-179,255-266, attention.py:254,340).
+ *   tc_groupnorm_coop_grid   > 0: the grid it would launch; 0: not this kernel's problem (caller keeps tc_groupnorm).
+ *   tc_groupnorm_coop        TC_ESHAPE where _grid says 0.  workspace: tc_groupnorm_coop_workspace() bytes (16-byte aligned).
+ *     sync: tc_groupnorm_coop_sync_bytes(samples) bytes of int32 counters, ZERO before the first call; the kernel leaves
+ *     them zero, so one buffer serves every later call on the same stream order (never shared by concurrent streams).
+ *   tc_groupnorm_coop_plan   the decomposition for a given number of co-resident blocks (host-only arithmetic: CPU tests). */
+int tc_groupnorm_coop_grid(int32_t samples, int32_t rows, int32_t c);
+int64_t tc_groupnorm_coop_workspace(int32_t samples, int32_t rows, int32_t c);
+int64_t tc_groupnorm_coop_sync_bytes(int32_t samples);
+int tc_groupnorm_coop(const tc_bf16* x, tc_bf16* y, const float* gamma, const float* beta, int32_t samples, int32_t rows,
+                      int32_t c, float eps, int32_t silu, void* workspace, int64_t workspace_bytes, void* sync,
+                      int64_t sync_bytes, void* stream);
+int tc_groupnorm_coop_plan(int32_t samples, int32_t rows, int32_t c, int32_t capacity, int32_t* out6);
 
 /* ABI 10 -- GroupNorm(+SiLU) as a PROLOGUE of the convolution that consumes it (lvdm/basics.py:76-87 in front of
  * lvdm/modules/networks/openaimodel3d.py:154,179 [ResBlock in_layers / out_layers] and :255-266 [TemporalConvBlock]): every

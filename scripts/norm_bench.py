@@ -12,10 +12,22 @@ print("TC_GN_BLOCKS", os.environ.get("TC_GN_BLOCKS"))
 
 
 def gn(samples, rows, c, tag):
+    """Three arms, interleaved in one process: TC_GN_COOP=0 (one-pass where a slab fits a block, else three launches), the
+    default routing, TC_GN_COOP=2 (the cooperative kernel wherever a plan exists).  TB/s on the ALGORITHMIC bytes (2 B read +
+    2 B written per element), the figure bench.py's roofline_hbm quotes."""
     x = torch.randn(samples * rows, c, device=dev).to(BF)
     g, b = torch.ones(c, device=dev), torch.zeros(c, device=dev)
-    ms = timeit(lambda: hip.groupnorm(x, g, b, samples=samples, rows=rows, eps=1e-5, silu=True))
-    print(f"groupnorm {tag:22s} s={samples:3d} rows={rows:7d} c={c:5d}  {ms*1e3:8.1f} us  {6.0*x.numel()/ms/1e9:7.2f} TB/s")
+    out = []
+    for mode in ("0", None, "2"):
+        if mode is None:
+            os.environ.pop("TC_GN_COOP", None)
+        else:
+            os.environ["TC_GN_COOP"] = mode
+        grid = hip.lib.tc_groupnorm_coop_grid(samples, rows, c)
+        ms = timeit(lambda: hip.groupnorm(x, g, b, samples=samples, rows=rows, eps=1e-5, silu=True))
+        out.append(f"{ms*1e3:7.1f} us {4.0*x.numel()/ms/1e9:5.2f} TB/s" + (f" (coop grid {grid})" if grid else " (no coop)"))
+    os.environ.pop("TC_GN_COOP", None)
+    print(f"groupnorm {tag:18s} s={samples:3d} rows={rows:7d} c={c:5d} | base {out[0]} | default {out[1]} | coop {out[2]}")
 
 
 def ln(rows, c, tag):
@@ -25,8 +37,8 @@ def ln(rows, c, tag):
     print(f"layernorm {tag:22s} rows={rows:7d} c={c:5d}  {ms*1e3:8.1f} us  {4.0*x.numel()/ms/1e9:7.2f} TB/s")
 
 
-gn(2, 40960, 320, "L0 clip-wide"); gn(32, 2560, 320, "L0 per-frame"); gn(32, 2560, 960, "L0 per-frame 960")
-gn(2, 10240, 640, "L1 clip-wide"); gn(32, 640, 640, "L1 per-frame"); gn(2, 2560, 1280, "L2 clip-wide")
+gn(2, 40960, 320, "L0 clip-wide"); gn(32, 2560, 320, "L0 per-frame"); gn(32, 2560, 640, "L0 per-frame 640"); gn(32, 2560, 960, "L0 per-frame 960")
+gn(2, 10240, 640, "L1 clip-wide"); gn(32, 640, 640, "L1 per-frame"); gn(32, 640, 1920, "L1 per-frame 1920"); gn(2, 2560, 1280, "L2 clip-wide")
 gn(32, 160, 1280, "L2 per-frame"); gn(2, 640, 1280, "L3 clip-wide"); gn(32, 40, 1280, "L3 per-frame")
 gn(16, 163840, 128, "dec L0 per-frame"); gn(1, 2621440, 128, "dec L0 clip-wide"); gn(16, 40960, 256, "dec L1 per-frame")
 gn(16, 10240, 512, "dec L2 per-frame")

@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libtooncrafter_hip.so")
 
-TC_ABI_VERSION = 10
+TC_ABI_VERSION = 11
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_GEGLU = 0, 1, 2, 3
 GATHER_LINEAR, GATHER_CONV3x3, GATHER_CONVT3 = 0, 1, 2
 
@@ -120,6 +120,12 @@ SYMBOLS = {
     "tc_ddim_step": (C.c_int, [C.POINTER(TcDdimParams), C.c_void_p, C.c_int64, C.c_void_p]),
     "tc_gemm_ws_eligible": (C.c_int, [C.POINTER(TcGemmParams)]),
     "tc_gemm_gn_rows": (C.c_int, [C.POINTER(TcGemmParams)]),
+    "tc_groupnorm_coop_grid": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
+    "tc_groupnorm_coop_workspace": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "tc_groupnorm_coop_sync_bytes": (C.c_int64, [C.c_int32]),
+    "tc_groupnorm_coop": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                    C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "tc_groupnorm_coop_plan": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "tc_groupnorm_part": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "tc_groupnorm_scale_shift": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float,

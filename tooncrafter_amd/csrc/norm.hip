@@ -21,6 +21,7 @@
 // Algorithmic traffic: read x twice, write y once (the second read mostly hits the 256 MiB
 // Infinity Cache for UNet-sized tensors).
 #include "common.h"
+#include "gn_route.h"
 
 #include <stdlib.h>
 
@@ -586,35 +587,24 @@ extern "C" int tc_groupnorm(const tc_bf16* x, tc_bf16* y, const float* gamma, co
   {
     // single-pass kernel when a (sample, unit) slab fits the registers of one block (TC_GN_ONEPASS=0: never)
     static const bool onepass = [] { const char* e = getenv("TC_GN_ONEPASS"); return !(e && e[0] == '0'); }();
-    const int cpg = c / 32;
-    int u = cpg;
-    while (u % 8) u += cpg;                                       // lcm(8, cpg) = U channels per unit
-    const int vu = u / 8, gu = u / cpg;
-    if (onepass && (c % u) == 0 && gu <= 4 && vu <= 64 && tc_aligned16(gamma) && tc_aligned16(beta)) {
-      const int64_t nvec = (int64_t)rows * vu;
+    const GnOnepass op = gn_onepass_rule(samples, rows, c);
+    const int u = op.u, vu = op.vu;
+    if (onepass && op.nv && tc_aligned16(gamma) && tc_aligned16(beta)) {
       const dim3 grid(c / u, samples);
       const bf16_t* xb = reinterpret_cast<const bf16_t*>(x);
       bf16_t* yb = reinterpret_cast<bf16_t*>(y);
-      auto fits = [&](int t, int nv) { return (int64_t)((rows + t / vu - 1) / (t / vu)) <= nv; };
       // measured (profiles/r02_gn_onepass_ab.txt): wins 13-32 % where the grid fills the chip (per-frame norms of levels
       // 1-3) or the tensor is tiny (level-3 clip-wide, 3 MB); LOSES with 64 blocks on a 13 MB tensor (level-2
       // clip-wide: 20 -> 31 us) and is neutral at level 0 (a 512-thread / 26-vector instance: dropped)
-      const int64_t nblk = (int64_t)(c / u) * samples;
-      const int64_t bytes = nvec * 16 * samples * (c / u);
-      bool done = nblk >= 128 || bytes <= (4 << 20);
-      if (!done) {}
-      else if (fits(256, 4)) {
+      if (op.nv == 4) {
         if (silu) hipLaunchKernelGGL((gn_onepass_kernel<256, 4, true>), grid, dim3(256), 0, s, xb, yb, gamma, beta, rows, c, vu, eps);
         else hipLaunchKernelGGL((gn_onepass_kernel<256, 4, false>), grid, dim3(256), 0, s, xb, yb, gamma, beta, rows, c, vu, eps);
-      } else if (fits(256, 13)) {
+      } else {
         if (silu) hipLaunchKernelGGL((gn_onepass_kernel<256, 13, true>), grid, dim3(256), 0, s, xb, yb, gamma, beta, rows, c, vu, eps);
         else hipLaunchKernelGGL((gn_onepass_kernel<256, 13, false>), grid, dim3(256), 0, s, xb, yb, gamma, beta, rows, c, vu, eps);
       }
-      else done = false;
-      if (done) {
-        TC_LAUNCH_CHECK();
-        return TC_OK;
-      }
+      TC_LAUNCH_CHECK();
+      return TC_OK;
     }
   }
   int nch, cr;

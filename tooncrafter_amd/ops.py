@@ -115,6 +115,10 @@ class HipOps:
         # ABI 10: GroupNorm(+SiLU) applied inside the convolution that consumes it (gn_conv -> tc_groupnorm_scale_shift +
         # tc_conv_gn_bf16, csrc/conv_halo.hip).  OFF by default: the kernel was written without GPU access
         self.gn_fuse = os.environ.get("TC_GN_FUSE", "0") == "1"
+        # ABI 11: cooperative single-launch GroupNorm (csrc/gn_coop.hip).  Its blocks wait for each other, so two such launches
+        # must never run concurrently on two streams: off when the guided passes run on their own streams (TC_CFG_STREAMS=1)
+        self.gn_coop = os.environ.get("TC_CFG_STREAMS", "0") != "1"
+        self._gn_sync_buf = {}
         self.gn_fuse_calls = {"fused": 0, "separate": 0}
 
     # ------------------------------------------------------------------ workspace
@@ -449,6 +453,19 @@ class HipOps:
         return out
 
     # ------------------------------------------------------------------ norms
+    def _gn_sync(self, device):
+        """The cooperative GroupNorm's counters (zero before the first call; the kernel leaves them zero): one buffer per
+        device for the process' lifetime.  Must exist before a hipGraph capture starts (a captured allocation would live in
+        the graph's private pool): the models run one eager forward before they capture, which creates it."""
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        buf = self._gn_sync_buf.get(key)
+        if buf is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("groupnorm: first use of the cooperative kernel inside a stream capture -- run the "
+                                   "operator once eagerly first (its counter buffer must not be a captured allocation)")
+            buf = self._gn_sync_buf[key] = torch.zeros(65536 * 4, dtype=torch.int32, device=device)
+        return buf
+
     def groupnorm(self, x, gamma, beta, *, samples, rows, eps, silu=False, part=None):
         """x: contiguous [samples*rows, C]; statistics over (rows, C/32) per (sample, group).  `part` (a GnPart from
         the gemm that produced x, or None): statistics from the producer's partial sums -- one pass over x, not two."""
@@ -467,6 +484,14 @@ class HipOps:
             _lib.check(self.lib.tc_groupnorm_part(x.data_ptr(), y.data_ptr(), gp, bp, part.sums.data_ptr(), part.rows, samples,
                                                   rows, c, float(eps), 1 if silu else 0, ws.data_ptr(), nbytes, _stream()),
                        "tc_groupnorm_part")
+            return y
+        if self.gn_coop and self.lib.tc_groupnorm_coop_grid(samples, rows, c) > 0:
+            sync = self._gn_sync(x.device)
+            nb = self.lib.tc_groupnorm_coop_workspace(samples, rows, c)
+            ws = self._workspace(nb, x.device)
+            _lib.check(self.lib.tc_groupnorm_coop(x.data_ptr(), y.data_ptr(), gp, bp, samples, rows, c, float(eps),
+                                                  1 if silu else 0, ws.data_ptr(), nb, sync.data_ptr(), sync.numel() * 4,
+                                                  _stream()), "tc_groupnorm_coop")
             return y
         _lib.check(self.lib.tc_groupnorm(x.data_ptr(), y.data_ptr(), gp, bp, samples,
                                          rows, c, float(eps), 1 if silu else 0, ws.data_ptr(), nbytes, _stream()),
