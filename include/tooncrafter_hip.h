@@ -228,39 +228,11 @@ int tc_groupnorm_part(const tc_bf16* x, tc_bf16* y, const float* gamma, const fl
                       int32_t part_rows, int32_t samples, int32_t rows, int32_t c, float eps, int32_t silu,
                       void* workspace, int64_t workspace_bytes, void* stream);
 
-/* ABI 11 -- the same operator as ONE launch that reads x once and writes y once (csrc/gn_coop.hip): the tensor is held in
- * the chip's register files by a grid of co-resident blocks that meet per sample at an atomic counter; for the tensors
- * whose (sample, channel-unit) slabs do not fit one block (UNet level 0, the clip-wide norms of levels 1 / 2: GroupNormSpecific
- * and nn.GroupNorm + SiLU of lvdm/basics.py:76-87, openaimodel3d.py:152-154,176-179,255-266, attention.py:254,340).
- *   tc_groupnorm_coop_grid   > 0: the grid it would launch; 0: not this kernel's problem (caller keeps tc_groupnorm).
- *   tc_groupnorm_coop        TC_ESHAPE where _grid says 0.  workspace: tc_groupnorm_coop_workspace() bytes (16-byte aligned).
- *     sync: tc_groupnorm_coop_sync_bytes(samples) bytes of int32 counters, ZERO before the first call; the kernel leaves
- *     them zero, so one buffer serves every later call on the same stream order (never shared by concurrent streams).
- *   tc_groupnorm_coop_plan   the decomposition for a given number of co-resident blocks (host-only arithmetic: CPU tests). */
-int tc_groupnorm_coop_grid(int32_t samples, int32_t rows, int32_t c);
-int64_t tc_groupnorm_coop_workspace(int32_t samples, int32_t rows, int32_t c);
-int64_t tc_groupnorm_coop_sync_bytes(int32_t samples);
-int tc_groupnorm_coop(const tc_bf16* x, tc_bf16* y, const float* gamma, const float* beta, int32_t samples, int32_t rows,
-                      int32_t c, float eps, int32_t silu, void* workspace, int64_t workspace_bytes, void* sync,
-                      int64_t sync_bytes, void* stream);
-int tc_groupnorm_coop_plan(int32_t samples, int32_t rows, int32_t c, int32_t capacity, int32_t* out6);
-
-/* ABI 10 -- GroupNorm(+SiLU) as a PROLOGUE of the convolution that consumes it (lvdm/basics.py:76-87 in front of
- * lvdm/modules/networks/openaimodel3d.py:154,179 [ResBlock in_layers / out_layers] and :255-266 [TemporalConvBlock]): every
- * GroupNorm of those blocks feeds a 3x3 / (3,1,1) convolution, so the normalised tensor need not exist.
- *   tc_groupnorm_scale_shift: the statistics pass alone; scale_shift [samples][2][c] fp32 = per (sample, channel)
- *     scale = rstd * gamma and shift = beta - mean * scale.  workspace: tc_groupnorm_workspace() bytes.
- *   tc_conv_gn_bf16: C = epilogue(conv(act(x * scale + shift)) ...) -- TcGemmParams as for tc_gemm_bf16 (gather CONV3x3
- *     stride 1 / pad 1 or CONVT3; a = the UN-normalised x), act = SiLU if silu else identity, rounded to bf16 exactly where
- *     tc_groupnorm would have stored it; zero padding applies to the activation (outside the image the operand is 0).
- *     gn_rows = output rows per GroupNorm sample (H*W for per-frame statistics, T*H*W for clip-wide ones).  Taken only by
- *     the tap-reuse kernel (csrc/conv_halo.hip): TC_ESHAPE for anything tc_conv_gn_eligible refuses -- the caller then runs
- *     tc_groupnorm + tc_gemm_bf16.  OPT-IN on the host side (TC_GN_FUSE=1); see DESIGN.md 5.5 (12). */
-int tc_groupnorm_scale_shift(const tc_bf16* x, const float* gamma, const float* beta, int32_t samples, int32_t rows,
-                             int32_t c, float eps, float* scale_shift, void* workspace, int64_t workspace_bytes,
-                             void* stream);
-int tc_conv_gn_eligible(const TcGemmParams* p, int32_t gn_rows);
-int tc_conv_gn_bf16(const TcGemmParams* p, const float* scale_shift, int32_t gn_rows, int32_t silu, void* stream);
+/* ABI 11 removed the three ABI-10 entry points tc_groupnorm_scale_shift / tc_conv_gn_eligible / tc_conv_gn_bf16 -- GroupNorm
+ * applied inside the convolution that consumes it: parity-green on the GPU and 4 % SLOWER per clip than the two operators
+ * (profiles/r05_fuse_clip_ab.txt).  A cooperative single-launch GroupNorm measured in the same round
+ * (x read once, blocks meeting at an atomic counter) was correct and slower on every shape as well
+ * (profiles/r05_gn_coop_bench.txt) and never entered the ABI; its source is kept as scripts/experiments/gn_coop.hip.txt. */
 
 /* LayerNorm over the last axis of [rows, C] (attention.py:225-227), eps 1e-5, affine. */
 int tc_layernorm(const tc_bf16* x, tc_bf16* y, const float* gamma, const float* beta,

@@ -1,8 +1,12 @@
 """Oracle (test infrastructure): the two OpenCLIP ViT-H/14 towers as the reference drives them, row f2.
 
-PARITY UNPINNED.  The arithmetic lives in a third-party package that is absent from /root/reference and from
-this image: `open_clip_torch==2.22.0` (reference requirements.txt:22; `open_clip.create_model_and_transforms
-("ViT-H-14", pretrained="laion2b_s32b_b79k")`, lvdm/modules/encoders/condition.py:188,307).  What follows
+PINNED (round 5) to an independent third-party implementation: HuggingFace `transformers`' CLIPVisionModel / CLIPTextModel at
+the ViT-H/14 geometry on seeded weights (tests/golden/make_openclip_golden.py -> tests/golden/openclip_hf.npz; replayed by
+tests/test_openclip_golden_cpu.py: 5e-7 / 6e-7, and the golden separates 'penultimate' from 'last' by 0.21).  The arithmetic
+the reference binds lives in a package that is absent from /root/reference and from this image: `open_clip_torch==2.22.0`
+(reference requirements.txt:22; `open_clip.create_model_and_transforms("ViT-H-14", pretrained="laion2b_s32b_b79k")`,
+lvdm/modules/encoders/condition.py:188,307), so the pin is against transformers under the published open_clip -> transformers
+parameter renaming, not against open_clip itself.  What follows
 restates its published architecture (open_clip/transformer.py @ v2.22.0: VisionTransformer, Transformer,
 ResidualAttentionBlock = x + attn(ln_1(x)); x + mlp(ln_2(x)), nn.MultiheadAttention with a fused
 in_proj, MLP c_fc -> GELU(erf) -> c_proj, no LayerScale for ViT-H) along the exact sequence of attribute
@@ -13,8 +17,7 @@ accesses of the reference's own call sites:
     the last resblock is skipped), causal attn_mask, ln_final -> (B, 77, 1024)
 State-dict keys are open_clip's (`visual.conv1.weight`, `visual.transformer.resblocks.N.attn.in_proj_weight`,
 `token_embedding.weight`, ...), i.e. what a ToonCrafter checkpoint stores under `embedder.model.*` and
-`cond_stage_model.model.*`.  No golden vector exists for these functions; tests compare the HIP path with this
-restatement only, and DESIGN.md lists the parity of this row as partial.
+`cond_stage_model.model.*`.
 """
 from __future__ import annotations
 

@@ -24,25 +24,15 @@ struct Rng {
 
 typedef std::vector<double> Vec;
 
-// gn_rows > 0: the GroupNorm prologue (ABI 10) -- the halo vectors become x * scale + shift with the table offsets of
-// chx::gn_table_offset (no SiLU here: integers keep every sum exact; pixels outside the image stay zero)
 template <int GATHER, int WM, int KS>
-static int run(int frames, int h, int w, int cin, int n, int lda, const char* tag, int gn_rows = 0) {
+static int run(int frames, int h, int w, int cin, int n, int lda, const char* tag) {
   using S = Shape<GATHER, WM>;
   const int taps = S::TAPS, hw = h * w, m = frames * hw, K = taps * cin;
   Rng rng{12345};
   Vec x((size_t)m * lda), wt((size_t)n * K), out((size_t)m * n, NAN), ref((size_t)m * n, 0.0);
   for (auto& v : x) v = rng.next(-3, 3);
   for (auto& v : wt) v = rng.next(-2, 2);
-  const int samples = gn_rows > 0 ? m / gn_rows : 0;
-  Vec ss((size_t)samples * 2 * cin), xn = x;                       // [samples][2][cin]; xn = what the convolution sees
-  if (gn_rows > 0) {
-    for (int s = 0; s < samples; ++s)
-      for (int c = 0; c < cin; ++c) { ss[((size_t)s * 2) * cin + c] = rng.next(1, 2); ss[((size_t)s * 2 + 1) * cin + c] = rng.next(-2, 2); }
-    for (int64_t r = 0; r < m; ++r)
-      for (int c = 0; c < cin; ++c)
-        xn[(size_t)r * lda + c] = x[(size_t)r * lda + c] * ss[((size_t)(r / gn_rows) * 2) * cin + c] + ss[((size_t)(r / gn_rows) * 2 + 1) * cin + c];
-  }
+  const Vec& xn = x;                                               // what the convolution sees
   // ---- direct convolution (weights tap-major: K = tap * cin + c; 3x3 tap = 3 (dy + 1) + (dx + 1); temporal tap = dt + 1)
   for (int f = 0; f < frames; ++f)
     for (int y = 0; y < h; ++y)
@@ -103,11 +93,6 @@ static int run(int frames, int h, int w, int cin, int n, int lda, const char* ta
                   const int64_t byte = pt.row_lo * lda * 2 + hv.off + (int64_t)chunk * (BK * 2) + e * 2;
                   if (byte / 2 >= (int64_t)m * lda) { printf("%s: halo source outside the tensor\n", tag); exit(1); }
                   v = x[(size_t)(byte / 2)];
-                  if (gn_rows > 0) {                                      // transform_halo: g_sc / g_sh of this thread, this chunk
-                    const int64_t s0 = gn_table_offset<GATHER>(pt, h, w, gn_rows, cin, tid) + (int64_t)chunk * BK;
-                    if (s0 + cin + 8 > (int64_t)ss.size()) { printf("%s: scale / shift outside the table\n", tag); exit(1); }
-                    v = v * ss[(size_t)s0 + e] + ss[(size_t)s0 + cin + e];
-                  }
                 }
                 sA[(size_t)hv.lds / 16 * 8 + e] = v;
               }
@@ -192,8 +177,5 @@ int main() {
   rc |= run<GATHER_T3, 2, 1>(32, 2, 5, 64, 160, 96, "t3 32x(2x5) 64->160 lda 96");
   rc |= run<GATHER_T3, 4, 1>(16, 8, 5, 64, 160, 64, "t3 tall 16x(8x5) 64->160");
   rc |= run<GATHER_T3, 2, 2>(16, 2, 5, 256, 160, 256, "t3 K split 16x(2x5) 256->160");
-  rc |= run<GATHER_3x3, 2, 1>(4, 10, 16, 128, 160, 128, "3x3 + GroupNorm, a sample per frame", 10 * 16);
-  rc |= run<GATHER_3x3, 4, 1>(4, 20, 16, 64, 160, 64, "3x3 tall + GroupNorm, two frames per sample", 2 * 20 * 16);
-  rc |= run<GATHER_T3, 2, 2>(32, 2, 5, 256, 160, 256, "t3 K split + GroupNorm, a sample per clip", 16 * 10);
   return rc;
 }

@@ -22,10 +22,8 @@ def _f(t):
 class EmuOps:
     name = "emu"
 
-    def __init__(self, round_bf16=True, ln_fusion_k=None, gn_rows=0, ff_fused_c=None, tb_fused_c=None, gn_fuse=False):
+    def __init__(self, round_bf16=True, ln_fusion_k=None, gn_rows=0, ff_fused_c=None, tb_fused_c=None):
         self.round = round_bf16
-        self.gn_fuse = gn_fuse               # tests only: gn_conv takes the one-pass route (ABI 10) where the library's shape rule allows
-        self.gn_fuse_calls = {"fused": 0, "separate": 0}
         self.ff_fused_c = ff_fused_c         # tests only: width whose feed-forward takes the one-launch route (the library: 320)
         self.ff_fused_calls = 0
         self.tb_fused_c = tb_fused_c         # tests only: width whose temporal self-attention takes the one-launch route (library: 320)
@@ -218,50 +216,7 @@ class EmuOps:
             y = F.silu(y)
         return self._out(y.permute(0, 2, 1).reshape(samples * rows, c)).contiguous()
 
-    # ---- ABI 10: GroupNorm folded into its convolution (HipOps.gn_conv / tc_groupnorm_scale_shift / tc_conv_gn_bf16)
-    def groupnorm_scale_shift(self, x, gamma, beta, *, samples, rows, eps):
-        """[samples, 2, C] fp32: scale = rstd * gamma, shift = beta - mean * scale (statistics as gn_finalize: fp64 E[x^2] - mean^2)."""
-        c = x.shape[1]
-        cpg = c // 32
-        xd = x.double().reshape(samples, rows, 32, cpg)
-        mean = xd.mean(dim=(1, 3))
-        var = ((xd * xd).mean(dim=(1, 3)) - mean * mean).clamp_min(0.0)
-        rstd = (1.0 / torch.sqrt(var + eps)).float()
-        scale = rstd.repeat_interleave(cpg, 1) * gamma.float()
-        shift = beta.float() - mean.float().repeat_interleave(cpg, 1) * scale
-        return torch.stack([scale, shift], 1).contiguous()
-
-    def gn_conv_eligible(self, x, w, conv, gn_rows):
-        """csrc/conv_halo.hip conv_halo_launch's shape rule, restated (10 x 16-pixel / 10-pixel x 16-frame patches, one
-        GroupNorm sample per patch, 160-column tiles)."""
-        if not self.gn_fuse or conv is None or x.shape[1] != conv["cin"] or conv["cin"] % 64 or w.shape[0] % 160:
-            return False
-        h, wd, frames = conv["h_out"], conv["w_out"], conv["frames"]
-        if conv["kind"] == "3x3":
-            if conv.get("stride", 1) != 1 or conv.get("upsample", False) or conv.get("pad", 1) != 1 or h % 10 or wd % 16:
-                return False
-            if conv.get("h_in", h) != h or conv.get("w_in", wd) != wd:
-                return False
-            unit = h * wd
-        else:
-            if conv.get("t_len", 1) != 16 or frames % 16 or (h * wd) % 10:
-                return False
-            unit = 16 * h * wd
-        return gn_rows > 0 and gn_rows % unit == 0 and (frames * h * wd) % gn_rows == 0
-
     def gn_conv(self, x, gamma, beta, w, bias=None, *, samples, rows, eps, conv, silu=True, part=None, **kw):
-        if self.gn_conv_eligible(x, w, conv, rows):
-            # what the kernel does: y = act(x * scale + shift) in fp32, rounded to bf16, as the convolution's operand
-            self.gn_fuse_calls["fused"] += 1
-            ss = self.groupnorm_scale_shift(x, gamma, beta, samples=samples, rows=rows, eps=eps)
-            c = x.shape[1]
-            y = _f(x).reshape(samples, rows, c) * ss[:, 0][:, None, :] + ss[:, 1][:, None, :]
-            if silu:
-                y = F.silu(y)
-            out = self.gemm(self._out(y.reshape(samples * rows, c)).contiguous(), w, bias, conv=conv,
-                            **{k: v for k, v in kw.items() if k != "gn_stats"})
-            return (out, None) if kw.get("gn_stats") else out
-        self.gn_fuse_calls["separate"] += 1
         h = self.groupnorm(x, gamma, beta, samples=samples, rows=rows, eps=eps, silu=silu, part=part)
         return self.gemm(h, w, bias, conv=conv, **kw)
 

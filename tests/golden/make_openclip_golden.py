@@ -84,8 +84,8 @@ def _layers_to_hf(sd, n_layers, d, pre):
     return out
 
 
-def to_hf_vision(sd, cfg):
-    p = "vision_model."
+def to_hf_vision(sd, cfg, p=""):
+    """`p`: transformers <= 4 nests the tower under "vision_model." / "text_model."; 5.x registers it at the top level."""
     out = _layers_to_hf(sd, cfg["layers"], cfg["width"], p)
     out.update({p + "embeddings.class_embedding": sd["class_embedding"], p + "embeddings.patch_embedding.weight": sd["conv1.weight"],
                 p + "embeddings.position_embedding.weight": sd["positional_embedding"],
@@ -94,13 +94,16 @@ def to_hf_vision(sd, cfg):
     return out
 
 
-def to_hf_text(sd, cfg):
-    p = "text_model."
+def to_hf_text(sd, cfg, p=""):
     out = _layers_to_hf(sd, cfg["layers"], cfg["width"], p)
     out.update({p + "embeddings.token_embedding.weight": sd["token_embedding.weight"],
                 p + "embeddings.position_embedding.weight": sd["positional_embedding"],
                 p + "final_layer_norm.weight": sd["ln_final.weight"], p + "final_layer_norm.bias": sd["ln_final.bias"]})
     return out
+
+
+def _prefix(model, inner):
+    return inner + "." if any(k.startswith(inner + ".") for k in model.state_dict()) else ""
 
 
 def _load(model, hf_sd):
@@ -118,7 +121,8 @@ def hf_vision_tokens(sd, image, cfg):
                          num_attention_heads=cfg["heads"], image_size=cfg["image"], patch_size=cfg["patch"], hidden_act="gelu",
                          layer_norm_eps=1e-5, attention_dropout=0.0, projection_dim=1024)
     c._attn_implementation = "eager"
-    m = _load(CLIPVisionModel(c), to_hf_vision(sd, cfg))
+    m = CLIPVisionModel(c)
+    m = _load(m, to_hf_vision(sd, cfg, _prefix(m, "vision_model")))
     with torch.no_grad():
         return m(pixel_values=image).last_hidden_state
 
@@ -130,10 +134,12 @@ def hf_text_tokens(sd, tokens, cfg):
                        hidden_act="gelu", layer_norm_eps=1e-5, attention_dropout=0.0, projection_dim=1024,
                        bos_token_id=cfg["vocab"] - 2, eos_token_id=cfg["vocab"] - 1, pad_token_id=0)
     c._attn_implementation = "eager"
-    m = _load(CLIPTextModel(c), to_hf_text(sd, cfg))
+    m = CLIPTextModel(c)
+    m = _load(m, to_hf_text(sd, cfg, _prefix(m, "text_model")))
+    ln = (m.text_model if hasattr(m, "text_model") else m).final_layer_norm
     with torch.no_grad():
         hs = m(input_ids=tokens, output_hidden_states=True).hidden_states
-        return m.text_model.final_layer_norm(hs[-2]), m.text_model.final_layer_norm(hs[-1])
+        return ln(hs[-2]), ln(hs[-1])
 
 
 # ---------------------------------------------------------------- tokeniser
@@ -168,8 +174,6 @@ def learn_merges(words, n_merges=220):
         if not counts:
             break
         best = max(counts.items(), key=lambda kv: kv[1])[0]
-        if counts[best] < 2:
-            break
         merges.append(best)
         for s in seqs:
             i = 0
@@ -195,16 +199,29 @@ def hf_token_ids(merges, prompts, context=77):
     vocab = open_clip_vocab(merges)
     tk = CLIPTokenizer(vocab=vocab, merges=[tuple(m.split()) for m in merges])
     out = []
+    import html
     for p in prompts:
-        out.append(tk(p, add_special_tokens=True)["input_ids"])
+        # open_clip's basic_clean un-escapes HTML entities (twice) before anything else; transformers has no such step, so it
+        # is given the un-escaped text: the pin covers case folding, whitespace, the split regex and the BPE merges
+        out.append(tk(html.unescape(html.unescape(p)).strip(), add_special_tokens=True)["input_ids"])
     return out, vocab
+
+
+def tokenizer_golden():
+    merges = learn_merges(CORPUS)
+    ids, vocab = hf_token_ids(merges, PROMPTS)
+    with open(os.path.join(HERE, "clip_bpe_hf.json"), "w") as f:
+        json.dump({"merges": merges, "prompts": PROMPTS, "hf_input_ids": ids, "n_vocab": len(vocab),
+                   "made_by": "transformers.CLIPTokenizer (tokenizers BPE) " + __import__("transformers").__version__}, f,
+                  ensure_ascii=True, indent=0)
+    print("tokeniser:", len(merges), "merges,", len(PROMPTS), "prompts; ids[1] =", ids[1])
 
 
 def main():
     torch.manual_seed(0)
     a = ARCH["ViT-H-14"]
     g = torch.Generator().manual_seed(20260922)
-    image = torch.randn(1, 3, 224, 224, generator=g)
+    image = torch.randn(1, 3, 224, 224, generator=g).half().float()          # stored as fp16: what is stored is what was run
     tokens = torch.randint(0, a["text"]["vocab"] - 2, (2, 77), generator=g)
     tokens[:, 0] = a["text"]["vocab"] - 2
     tokens[0, 20], tokens[0, 21:] = a["text"]["vocab"] - 1, 0                    # a short prompt: eot, then open_clip's zero padding
@@ -224,14 +241,8 @@ def main():
     np.savez_compressed(os.path.join(HERE, "openclip_hf.npz"), image=image.numpy().astype(np.float16), tokens=tokens.numpy(),
                         vision_tokens=yv.numpy(), text_tokens=yt.numpy(), tiny_image=img_t.numpy(), tiny_tokens=tok_t.numpy(),
                         tiny_vision_tokens=yv_t.numpy(), tiny_text_tokens=yt_t.numpy(), seed=np.int64(SEED))
-    merges = learn_merges(CORPUS)
-    ids, vocab = hf_token_ids(merges, PROMPTS)
-    with open(os.path.join(HERE, "clip_bpe_hf.json"), "w") as f:
-        json.dump({"merges": merges, "prompts": PROMPTS, "hf_input_ids": ids, "n_vocab": len(vocab),
-                   "made_by": "transformers.CLIPTokenizer (tokenizers BPE) " + __import__("transformers").__version__}, f,
-                  ensure_ascii=True, indent=0)
-    print("tokeniser:", len(merges), "merges,", len(PROMPTS), "prompts; ids[1] =", ids[1])
+    tokenizer_golden()
 
 
 if __name__ == "__main__":
-    main()
+    tokenizer_golden() if sys.argv[1:] == ["tokenizer"] else main()

@@ -1,5 +1,6 @@
 """Host-side pieces of the conditioning stack restated from third-party packages that are absent here
-(open_clip's tokeniser, kornia's resize): the mechanics are tested; parity with the packages is unpinned and the
+(open_clip's tokeniser, kornia's resize): the mechanics are tested here; the tokeniser's parity is pinned in
+test_openclip_golden_cpu.py (transformers.CLIPTokenizer), the resize's is unpinned and the
 modules say so."""
 import gzip
 

@@ -49,13 +49,12 @@ def write_conflicts(addrs):
 class HaloKernelModel:
     """One block of conv_halo_kernel<GATHER>, lane by lane."""
 
-    def __init__(self, gather, x, w, frames, h, wd, cin, n, lda=None, WM=2, KS=1, gn=None):
+    def __init__(self, gather, x, w, frames, h, wd, cin, n, lda=None, WM=2, KS=1):
         self.g, self.x, self.w = gather, x, w
         self.frames, self.h, self.wd, self.cin, self.n = frames, h, wd, cin, n
         self.lda = lda or cin
         self.WM, self.PY, self.threads = WM, 5 * WM, 128 * WM          # WM = 4: the tall 320-row patch on eight waves
         self.KS = KS                                                    # KS = 2: two 4-wave groups, each with half of the channel chunks
-        self.gn = gn                                                    # (ss [samples, 2, cin], rows per sample, silu): the GroupNorm prologue
         assert KS == 1 or (WM == 2 and (cin // TC_BK) % 2 == 0)
         self.taps = 9 if gather == CONV3x3 else 3
         self.hy = self.PY + 2 if gather == CONV3x3 else self.PY
@@ -116,10 +115,6 @@ class HaloKernelModel:
                 lds = pix * 128 + ((seg ^ (pix & 7)) << 4) if pix < self.npix else None
                 mine.append((off, lds))
             hv.append(mine)
-        if self.gn is not None:
-            ss, gn_rows, gn_silu = self.gn
-            any_row = img * self.hw if self.g == CONV3x3 else img * 16 * self.hw
-            gn_sample = any_row // gn_rows
 
         def fill_halo(c):
             for wave in range(2 * self.WM):
@@ -132,18 +127,11 @@ class HaloKernelModel:
                         continue
                     assert lds % 16 == 0 and lds + 16 <= self.a_bytes
                     if off is None:
-                        sA[lds // 16] = np.zeros(8)                      # outside the image: zero, also under GroupNorm
+                        sA[lds // 16] = np.zeros(8)                      # outside the image: zero
                     else:
                         byte = row_lo * self.lda * 2 + off + c * 128
                         row, col = divmod(byte // 2, self.lda)
                         val = self.x[row, col:col + 8].astype(np.float64)
-                        if self.gn is not None:
-                            # gn_base + chunk * 64: the thread's 8 channels are segment tid & 7 of the chunk
-                            ch0 = c * TC_BK + (tid & 7) * 8
-                            assert ch0 == col and row // gn_rows == gn_sample
-                            val = val * ss[gn_sample, 0, ch0:ch0 + 8] + ss[gn_sample, 1, ch0:ch0 + 8]
-                            if gn_silu:
-                                val = val / (1.0 + np.exp(-val))
                         sA[lds // 16] = val
 
         RSTEP = 16 * self.WM
@@ -321,29 +309,3 @@ def test_fragment_swizzle_choices():
         assert read_conflicts(addrs) == 0
 
 
-@pytest.mark.parametrize("gather,frames,h,wd,cin,n,gn_rows", [
-    (CONV3x3, 2, 20, 16, 128, 160, 20 * 16),        # per-frame statistics: one sample per frame, two patches per frame
-    (CONV3x3, 4, 10, 16, 64, 160, 2 * 10 * 16),     # a sample of two frames
-    (CONVT3, 32, 2, 5, 128, 160, 16 * 10),          # clip-wide statistics: one sample per clip
-])
-def test_groupnorm_prologue_of_the_halo_fill(gather, frames, h, wd, cin, n, gn_rows):
-    """ABI 10 (tc_conv_gn_bf16): the halo vectors are normalised in registers -- per-thread scale / shift of segment
-    tid & 7 of the chunk, the patch's sample from its first row, pixels outside the image left at zero."""
-    rng = np.random.default_rng(9)
-    m = frames * h * wd
-    taps = 9 if gather == CONV3x3 else 3
-    x = rng.integers(-3, 4, size=(m, cin)).astype(np.float64)
-    w = rng.integers(-2, 3, size=(n, taps * cin)).astype(np.float64)
-    samples = m // gn_rows
-    ss = np.stack([rng.integers(1, 3, size=(samples, cin)), rng.integers(-2, 3, size=(samples, cin))], 1).astype(np.float64)
-    for silu in (False, True):
-        model = HaloKernelModel(gather, x, w, frames, h, wd, cin, n, gn=(ss, gn_rows, silu))
-        tiles_m, _ = model.tiles()
-        out = np.full((m, n), np.nan)
-        for tm in range(tiles_m):
-            model.run_block(tm, 0, out)
-        y = x.reshape(samples, gn_rows, cin) * ss[:, 0][:, None, :] + ss[:, 1][:, None, :]
-        if silu:
-            y = y / (1.0 + np.exp(-y))
-        ref = direct_conv(gather, y.reshape(m, cin), w, frames, h, wd, cin, n)
-        assert np.allclose(out, ref, rtol=1e-12, atol=1e-9)

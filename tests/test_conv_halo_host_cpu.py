@@ -24,14 +24,14 @@ def test_shipped_index_functions_reproduce_the_convolution(tmp_path):
     print(r.stdout)
     assert r.returncode == 0, r.stdout[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
-    assert len(lines) == 11 and all(" ok " in l for l in lines), r.stdout
+    assert len(lines) == 8 and all(" ok " in l for l in lines), r.stdout
 
 
 def test_kernel_source_takes_its_formulas_from_the_header():
     """The point of the host check is lost if the kernel keeps private copies of the formulas: it must call the header."""
     src = open(os.path.join(ROOT, "tooncrafter_amd", "csrc", "conv_halo.hip")).read()
     for fn in ("chx::patch_of<", "chx::tiles_m<", "chx::halo_vec<", "chx::frag_a_hp0(", "chx::frag_a_addr(", "chx::frag_b_off(",
-               "chx::frag_b_chunk(", "chx::w_lrow(", "chx::w_chunk(", "chx::w_pass_live<", "chx::out_row(", "chx::w_k0(", "chx::tap_shift(", "chx::gn_table_offset<"):
+               "chx::frag_b_chunk(", "chx::w_lrow(", "chx::w_chunk(", "chx::w_pass_live<", "chx::out_row(", "chx::w_k0(", "chx::tap_shift("):
         assert fn in src, fn
     body = src[src.index("conv_halo_kernel(const TcGemmParams p"):]
     for private in ("pix * 128", "(hp << 7)", "m00 - p.w_out"):

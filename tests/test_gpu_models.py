@@ -313,8 +313,35 @@ def test_resampler_vs_reference_golden_and_full_size_oracle(hip):
     assert e_tiny < 2e-2 and e_full < 2e-2
 
 
+def test_openclip_towers_vs_transformers_golden(hip):
+    """Row f2 against the THIRD-PARTY golden (tests/golden/openclip_hf.npz: HuggingFace transformers' CLIP at the ViT-H/14
+    geometry on this repo's synthetic weights, tests/golden/make_openclip_golden.py): the HIP towers of lvdm/openclip.py,
+    driven through the reference's own classes (condition.py:215-231 text with layer='penultimate', :340-372 image tokens)."""
+    import numpy as np
+    from conftest import GOLDEN as GOLDEN_DIR
+    from tooncrafter_amd import synth
+    from tooncrafter_amd.lvdm.condition import FrozenOpenCLIPEmbedder, FrozenOpenCLIPImageEmbedderV2
+    g = np.load(os.path.join(GOLDEN_DIR, "openclip_hf.npz"))
+    emb_v = FrozenOpenCLIPImageEmbedderV2().eval()
+    synth.fill_module_(emb_v, prefix="embedder.", seed=int(g["seed"]))
+    emb_v = emb_v.to(DEV)
+    img = torch.from_numpy(g["image"].astype(np.float32)).to(DEV)
+    with torch.no_grad():
+        yv = _with_backend(hip, lambda: emb_v.model.visual.tokens(img)).cpu()
+    del emb_v
+    emb_t = FrozenOpenCLIPEmbedder(layer="penultimate").eval()
+    synth.fill_module_(emb_t, prefix="cond_stage_model.", seed=int(g["seed"]))
+    emb_t = emb_t.to(DEV)
+    with torch.no_grad():
+        yt = _with_backend(hip, lambda: emb_t(torch.from_numpy(g["tokens"]))).cpu()
+    e_v, e_t = rel_l2(yv, torch.from_numpy(g["vision_tokens"])), rel_l2(yt, torch.from_numpy(g["text_tokens"]))
+    print(f"openclip towers (HIP) vs transformers golden: ViT-H/14 vision {e_v:.3e} text {e_t:.3e}")
+    assert tuple(yv.shape) == (1, 257, 1280) and tuple(yt.shape) == (2, 77, 1024)
+    assert e_v < 3e-2 and e_t < 3e-2
+
+
 def test_openclip_towers_vs_oracle(hip):
-    """Row f2 (parity unpinned, see oracle/openclip.py): tiny towers and the full ViT-H/14 geometry -- vision
+    """Row f2 (the restatement itself is pinned to transformers: tests/test_openclip_golden_cpu.py): tiny towers and the full ViT-H/14 geometry -- vision
     32 layers x 16 heads of 80 over 257 tokens, text 23 of 24 layers x 16 heads of 64 over 77 causal tokens --
     against the fp32 CPU restatement on identical synthetic weights."""
     from oracle import openclip as oclip

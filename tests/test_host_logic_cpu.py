@@ -262,7 +262,7 @@ def _tiny_towers():
 
 
 def test_openclip_towers_host_logic():
-    """Row f2 (parity unpinned: open_clip is absent): the tower mirrors against oracle/openclip.py through the
+    """Row f2 (oracle/openclip.py itself is pinned to transformers, tests/test_openclip_golden_cpu.py): the tower mirrors against it through the
     exact-arithmetic operator contract -- patch GEMM + positional residual, class token, fused q|k projection,
     V^T by operand swap, head-dim-80 attention as GEMM/softmax/GEMM with K padding, V-bias folded into out_proj,
     causal text mask, penultimate layer."""

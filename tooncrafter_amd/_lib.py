@@ -120,18 +120,8 @@ SYMBOLS = {
     "tc_ddim_step": (C.c_int, [C.POINTER(TcDdimParams), C.c_void_p, C.c_int64, C.c_void_p]),
     "tc_gemm_ws_eligible": (C.c_int, [C.POINTER(TcGemmParams)]),
     "tc_gemm_gn_rows": (C.c_int, [C.POINTER(TcGemmParams)]),
-    "tc_groupnorm_coop_grid": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
-    "tc_groupnorm_coop_workspace": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
-    "tc_groupnorm_coop_sync_bytes": (C.c_int64, [C.c_int32]),
-    "tc_groupnorm_coop": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float,
-                                    C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
-    "tc_groupnorm_coop_plan": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "tc_groupnorm_part": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
-    "tc_groupnorm_scale_shift": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float,
-                                           C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
-    "tc_conv_gn_eligible": (C.c_int, [C.POINTER(TcGemmParams), C.c_int32]),
-    "tc_conv_gn_bf16": (C.c_int, [C.POINTER(TcGemmParams), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "tc_ff_geglu_fused_eligible": (C.c_int, [C.POINTER(TcFfParams)]),
     "tc_ff_geglu_fused": (C.c_int, [C.POINTER(TcFfParams), C.c_void_p]),
     "tc_temporal_attn_fused_eligible": (C.c_int, [C.POINTER(TcTbParams)]),

@@ -16,11 +16,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtooncrafter_hip.so")
-SOURCES = ["gemm.hip", "gemm_wide.hip", "gemm16.hip", "conv_halo.hip", "gemm8.hip", "ff_fused.hip", "tb_fused.hip", "gemm_ws.hip", "gemm_mx.hip", "attention.hip", "norm.hip", "gn_coop.hip", "elementwise.hip"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "gemm_epilogue.h"), os.path.join(CSRC, "gemm_persist.h"), os.path.join(CSRC, "conv_halo_index.h"), os.path.join(CSRC, "gn_route.h"),
+SOURCES = ["gemm.hip", "gemm_wide.hip", "gemm16.hip", "conv_halo.hip", "gemm8.hip", "ff_fused.hip", "tb_fused.hip", "gemm_ws.hip", "gemm_mx.hip", "attention.hip", "norm.hip", "elementwise.hip"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "gemm_epilogue.h"), os.path.join(CSRC, "gemm_persist.h"), os.path.join(CSRC, "conv_halo_index.h"),
            os.path.join(ROOT, "include", "tooncrafter_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+if os.environ.get("TC_TIMING_BUILDS") == "1":       # the timing-ablation / interval-trace instantiations (WRONG results by construction:
+    FLAGS.append("-DTC_TIMING_BUILDS")              # scripts/*_ablate*, *_trace.py); the product library does not contain them
 # per-source flags.  attention.hip: MFMA results straight into VGPRs (gfx950's register file is unified) -- by default
 # hipcc parks the score / output accumulators in AGPRs and the in-register softmax then pays 224 v_accvgpr_read/write
 # moves per 64-key tile
@@ -82,7 +84,7 @@ def build_torch_ops(force: bool = False, verbose: bool = True) -> str:
            f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
            *["-I" + p for p in ce.include_paths()], "-I" + os.path.join(rocm, "include"), "-I" + os.path.join(ROOT, "include"),
            TORCH_SRC, "-o", TORCH_LIB, "-L" + tlib, "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_hip",
-           "-L" + os.path.join(rocm, "lib"), "-lamdhip64", "-L" + HERE, "-ltooncrafter_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + tlib]
+           "-L" + HERE, "-ltooncrafter_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + tlib]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

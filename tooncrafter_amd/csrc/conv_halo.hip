@@ -1,7 +1,18 @@
 // Tap-reuse convolutions on 160x160 tiles, gfx950: the 3x3 (stride 1, pad 1) and the temporal (3,1,1) convolutions of the
-// UNet with the A operand of ALL taps read from ONE halo patch in LDS.  OPT-IN (TC_CONV_HALO=1|2, default off): written in a
-// session without GPU access, cross-compiled and index-checked on the CPU (tests/test_conv_halo_cpu.py mirrors every
-// address formula below in numpy), NOT yet run on an MI355X -- tests/test_gpu_conv_halo.py is the first thing to run.
+// UNet with the A operand of ALL taps read from ONE halo patch in LDS.  Written in round 4 without GPU access (index
+// arithmetic checked on the CPU: tests/test_conv_halo_cpu.py, tests/conv_halo_host_check.cpp); first executed in round 5, where
+// all of its GPU tests passed on the first run (profiles/r05_pytest_conv_halo_first_gpu_run.log).  MEASURED
+// (profiles/r05_conv_halo_bench.txt, r05_halo3x3_clip_ab.txt, r05_fuse_clip_ab.txt; same process / same lease, interleaved):
+//   3x3, level 0 / 1 (1024 / 512 patches):  1.03-1.07x the 160-tile implicit GEMM (tall patches 1.06-1.10x)
+//   3x3, level 2 (256 patches, K split inside the block):  1.15-1.27x
+//   temporal (3,1,1):  0.98x / 0.98x / 0.93x / 0.50x at levels 0 / 1 / 2 / 3 -- three taps re-use too little
+//   a clip with the 3x3 convolutions here: 8.29 / 8.30 vs 8.20 / 8.21 frames/s (+1.1 %)
+// so the ROUTING is: 3x3 convolutions of UNet levels 0-2 by default; the temporal geometry only on request
+// (TC_CONV_HALO_T3=1) and in the strict test mode.  Round 4 PREDICTED 1.3x from an additive model of the request traffic
+// (DESIGN.md 5.5 (11)); the A bytes fell 6.7x as designed and the time fell 5 %: the 160-tile K loop was not waiting for
+// those bytes.  The GroupNorm prologue this kernel carried (ABI 10, tc_conv_gn_bf16: normalise the halo in registers)
+// was parity-green and LOST 4 % of a clip (7.80 / 7.81 vs 8.15 / 8.18 frames/s: +8 % convolution time for -0.7 ms of
+// GroupNorm, whose statistics pass + finalize stay): removed in ABI 11.
 //
 // Why.  The implicit-GEMM kernels (gemm16.hip) request the A tile once per K-step = once per (tap, 64 channels): every
 // input pixel goes L2 -> LDS nine times per output-column tile (three times for the temporal taps).  The timing builds
@@ -61,25 +72,8 @@ using ChGeo = chx::Shape<GATHER, WM>;                      // TAPS, PY, HY, NPIX
 constexpr int CH_RED_OFF = 32 * 1024;                      // the hand-over area starts behind group 0's epilogue slabs
 constexpr int CH_RED_BYTES = 4 * CH_NT * CH_NT * 4 * 64 * 4;       // 4 waves x 25 MFMA tiles x 4 registers x 64 lanes x fp32 = 100 KiB
 
-// GN (ABI 10, tc_conv_gn_bf16): the convolution of silu(x * scale + shift) -- GroupNorm(+SiLU) of the A operand applied to the
-// halo vectors IN REGISTERS between their load and their ds_write (lvdm/basics.py:76-87 in front of openaimodel3d.py:154,179,
-// 255-266: every GroupNorm of a ResBlock / TemporalConvBlock feeds a convolution).  The normalised tensor is never written:
-// GroupNorm shrinks to its statistics pass (tc_groupnorm_scale_shift: per (sample, channel) scale = rstd * gamma and
-// shift = beta - mean * scale), the apply pass and the convolution's re-read of its output disappear.  A thread's halo
-// vectors all carry the SAME 8 channels (segment tid & 7 of the chunk), so it needs 8 + 8 floats per chunk; a patch lies
-// inside one GroupNorm sample (a frame for the 3x3, the clip for the temporal taps -- host-checked).  Same arithmetic and
-// roundings as gn_apply (fp32 fma, SiLU, round to bf16), so the MFMA operand is what the two-launch path would have read;
-// pixels outside the image stay ZERO (the reference pads the activation, not its input).  Cost: ~9 vector instructions per
-// halo element, 56 elements per thread and chunk against the chunk's 450 MFMAs per wave -- an implicit GEMM would pay it
-// nine times (once per tap), which is why this fusion only exists here.
-struct ChGn {
-  const float* ss;      // [samples][2][cin] fp32: scale row, shift row
-  int rows;             // output rows per GroupNorm sample
-  int silu;
-};
-
-template <int GATHER, int WM, int KS, bool GN>
-__global__ __launch_bounds__(128 * WM * KS, (WM == 2 && KS == 1) ? 2 : 1) void conv_halo_kernel(const TcGemmParams p, const int order, const ChGn gn) {
+template <int GATHER, int WM, int KS>
+__global__ __launch_bounds__(128 * WM * KS, (WM == 2 && KS == 1) ? 2 : 1) void conv_halo_kernel(const TcGemmParams p, const int order) {
   using G = ChGeo<GATHER, WM>;
   static_assert(KS == 1 || WM == 2, "the K split runs two 4-wave groups");
   constexpr int CH_A_BYTES = G::A_BYTES;
@@ -126,39 +120,10 @@ __global__ __launch_bounds__(128 * WM * KS, (WM == 2 && KS == 1) ? 2 : 1) void c
     hv_lds[i] = hvv.lds;
   }
   u32x4 hv[CH_NV];
-  f32x4 g_sc[2], g_sh[2];                                  // GN: scale / shift of this thread's 8 channels of the chunk
-  const float* gn_base = nullptr;
-  if (GN) gn_base = gn.ss + chx::gn_table_offset<GATHER>(pt, p.h_out, p.w_out, gn.rows, p.cin, tid);
   auto load_halo = [&](int chunk_idx) {
     const uint32_t soff = (uint32_t)chunk_idx * (TC_BK * 2);
 #pragma unroll
     for (int i = 0; i < CH_NV; ++i) hv[i] = buf_load16(a_rsrc, hv_off[i], soff);
-    if (GN) {
-      const float* s0 = gn_base + chunk_idx * TC_BK;
-      g_sc[0] = *reinterpret_cast<const f32x4*>(s0);
-      g_sc[1] = *reinterpret_cast<const f32x4*>(s0 + 4);
-      g_sh[0] = *reinterpret_cast<const f32x4*>(s0 + p.cin);
-      g_sh[1] = *reinterpret_cast<const f32x4*>(s0 + p.cin + 4);
-    }
-  };
-  // GN: normalise the loaded vectors in registers (before the step's wait + barrier: beside the other waves' MFMAs)
-  auto transform_halo = [&]() {
-    if (!GN) return;
-#pragma unroll
-    for (int i = 0; i < CH_NV; ++i) {
-      if (hv_off[i] != TC_OOB) {                           // outside the image / no such pixel: stays zero
-        float f[8];
-        unpack8(hv[i], f);
-        if (gn.silu) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) f[e] = silu_f(f[e] * (e < 4 ? g_sc[0][e] : g_sc[1][e - 4]) + (e < 4 ? g_sh[0][e] : g_sh[1][e - 4]));
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) f[e] = f[e] * (e < 4 ? g_sc[0][e] : g_sc[1][e - 4]) + (e < 4 ? g_sh[0][e] : g_sh[1][e - 4]);
-        }
-        hv[i] = pack8(f);
-      }
-    }
   };
   auto store_halo = [&]() {
 #pragma unroll
@@ -230,7 +195,6 @@ __global__ __launch_bounds__(128 * WM * KS, (WM == 2 && KS == 1) ? 2 : 1) void c
   const int nk = G::TAPS * nch;
   request_w(chx::w_k0(0, c0, p.cin), 0);
   load_halo(c0);
-  transform_halo();
   store_halo();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -245,7 +209,6 @@ __global__ __launch_bounds__(128 * WM * KS, (WM == 2 && KS == 1) ? 2 : 1) void c
     if (more) request_w(chx::w_k0(ntap, c0 + nc, p.cin), st ^ 1);
     if (refill) load_halo(c0 + nc);
     compute(st, chx::tap_shift(GATHER, ty, tx));
-    if (refill) transform_halo();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // own pieces of W(kb + 1) (and the halo vectors) have landed
     __syncthreads();                                       // every wave's fragment reads of this step are done
     if (refill) {
@@ -340,9 +303,9 @@ __global__ __launch_bounds__(128 * WM * KS, (WM == 2 && KS == 1) ? 2 : 1) void c
   epi_pass(ic<4>{});
 }
 
-int conv_halo_mode() {        // TC_CONV_HALO = 0 / unset never | 1 | 2 whenever the shape allows; read per call (A/B runs)
+int conv_halo_mode() {        // TC_CONV_HALO = 0 never | 1 / unset: the measured routing | 2 strict (tests): whenever the shape allows, else FAIL; read per call
   const char* e = getenv("TC_CONV_HALO");
-  return e ? atoi(e) : 0;
+  return e ? atoi(e) : 1;
 }
 int conv_halo_ksplit() {      // TC_CONV_HALO_KSPLIT = 0: never | 1 / unset: launches of at most 256 patches-blocks (one per CU) | 2: whenever cin / 64 is even
   const char* e = getenv("TC_CONV_HALO_KSPLIT");
@@ -355,8 +318,8 @@ int conv_halo_tall() {        // TC_CONV_HALO_TALL = 0 / unset: 160-row patches 
 
 }  // namespace
 
-// shape rules + launch.  gn.ss != nullptr: the GroupNorm prologue.  1 = launched (or would be: dry), 0 = not this kernel's problem
-static int conv_halo_launch(const TcGemmParams& p, int batch, hipStream_t s, bool dry, const ChGn& gn) {
+// shape rules + launch.  1 = launched (or would be: dry), 0 = not this kernel's problem
+static int conv_halo_launch(const TcGemmParams& p, int batch, hipStream_t s, bool dry) {
   if (p.gather != TC_GATHER_CONV3x3 && p.gather != TC_GATHER_CONVT3) return 0;
   if (p.act == TC_ACT_GEGLU || p.gn_part || p.a_norm || (p.n % CH_BN) != 0 || (p.cin % TC_BK) != 0 ||
       p.k != (p.gather == TC_GATHER_CONV3x3 ? 9 : 3) * p.cin) return 0;
@@ -374,11 +337,6 @@ static int conv_halo_launch(const TcGemmParams& p, int batch, hipStream_t s, boo
     if ((int64_t)17 * hw * p.lda * 2 >= 0x7fffff00LL) return 0;          // a patch spans the clip's 16 frames: 31-bit offsets
   }
   if (tiles_m * 160 != p.m) return 0;
-  if (gn.ss) {
-    // a patch must lie inside ONE GroupNorm sample: whole frames (3x3) / whole clips (temporal) per sample
-    const int64_t unit = p.gather == TC_GATHER_CONV3x3 ? (int64_t)hw : (int64_t)16 * hw;
-    if (batch != 1 || gn.rows <= 0 || (gn.rows % unit) != 0 || (p.m % gn.rows) != 0) return 0;
-  }
   const int tiles_n = p.n / CH_BN;
   const int tall = conv_halo_tall();
   const bool use_tall = tiles_tall > 0 && (tall == 2 || (tall == 1 && tiles_tall * tiles_n * batch >= 256));
@@ -392,11 +350,7 @@ static int conv_halo_launch(const TcGemmParams& p, int batch, hipStream_t s, boo
   const int nchunks = p.cin / TC_BK;
   const bool ksplit = !use_tall && (nchunks % 2) == 0 && nchunks >= 4 &&
                       (ksm == 2 || (ksm == 1 && tiles_m * tiles_n * batch <= 256));
-#define TC_LAUNCH_HALO(G, WM_, KS_, T_)                                                                                   \
-  do {                                                                                                                    \
-    if (gn.ss) hipLaunchKernelGGL((conv_halo_kernel<G, WM_, KS_, true>), grid, dim3(T_), 0, s, p, order, gn);            \
-    else hipLaunchKernelGGL((conv_halo_kernel<G, WM_, KS_, false>), grid, dim3(T_), 0, s, p, order, gn);                 \
-  } while (0)
+#define TC_LAUNCH_HALO(G, WM_, KS_, T_) hipLaunchKernelGGL((conv_halo_kernel<G, WM_, KS_>), grid, dim3(T_), 0, s, p, order)
   if (use_tall) {
     if (p.gather == TC_GATHER_CONV3x3) TC_LAUNCH_HALO(TC_GATHER_CONV3x3, 4, 1, 512);
     else TC_LAUNCH_HALO(TC_GATHER_CONVT3, 4, 1, 512);
@@ -414,58 +368,27 @@ static int conv_halo_launch(const TcGemmParams& p, int batch, hipStream_t s, boo
 // Decide whether the tap-reuse kernel takes this (already validated) convolution, and launch it.  1 = launched, 0 = not
 // taken, -1 = TC_CONV_HALO=2 ("strict", the parity tests) and a convolution was NOT taken: the caller fails the call, so a
 // test that passes under mode 2 has provably run this kernel and not a fallback.
+// Mode 1 (the default) is the measured routing: the 3x3 convolutions (1.03-1.27x), not the temporal ones (0.5-0.99x) unless
+// TC_CONV_HALO_T3=1; TC_CONV_HALO_3X3=0 keeps the 3x3 ones on the implicit GEMM as well (A/B runs).
 int tc_conv_halo_try(const TcGemmParams& p, int batch, hipStream_t s, bool dry) {
   const int mode = conv_halo_mode();
   if (mode == 0) return 0;
   if (p.gather != TC_GATHER_CONV3x3 && p.gather != TC_GATHER_CONVT3) return 0;
   if (mode == 1) {
-    // per-kind switches for the routing once the A/B of scripts/conv_halo_bench.py is in: TC_CONV_HALO_3X3=0 / TC_CONV_HALO_T3=0
-    // keep that kind on the implicit GEMM (strict mode ignores them)
-    const char* e = getenv(p.gather == TC_GATHER_CONV3x3 ? "TC_CONV_HALO_3X3" : "TC_CONV_HALO_T3");
-    if (e && e[0] == '0') return 0;
+    // a switch that selects among the IMPLICIT-GEMM kernels names the kernel under test / under measurement: keep out of its way
+    for (const char* sw : {"TC_GEMM_TILE16", "TC_GEMM8", "TC_GEMM_PIPE", "TC_GEMM_SPLITK", "TC_GEMM_WS", "TC_G16_ILV", "TC_G16_TALL",
+                           "TC_GEMM_WIDE", "TC_GEMM_ORDER", "TC_GEMM_NMAJOR"}) {
+      const char* e = getenv(sw);
+      if (e && e[0]) return 0;
+    }
+    if (p.gather == TC_GATHER_CONV3x3) {
+      const char* e = getenv("TC_CONV_HALO_3X3");
+      if (e && e[0] == '0') return 0;
+    } else {
+      const char* e = getenv("TC_CONV_HALO_T3");
+      if (!(e && e[0] == '1')) return 0;
+    }
   }
-  const int r = conv_halo_launch(p, batch, s, dry, ChGn{nullptr, 0, 0});
+  const int r = conv_halo_launch(p, batch, s, dry);
   return r ? 1 : (mode == 2 ? -1 : 0);
-}
-
-// ---- ABI 10: the convolution of GroupNorm(+SiLU)(x), statistics as a (scale, shift) table (tc_groupnorm_scale_shift)
-// (pointers = false: the eligibility question is asked with a geometry-only struct)
-static int conv_gn_check(const TcGemmParams& p, bool pointers) {
-  if (p.m <= 0 || p.n <= 0 || p.k <= 0) return TC_EINVAL;
-  if (pointers) {
-    if (!p.a || !p.w || !p.c) return TC_EINVAL;
-    if (!tc_aligned16(p.a) || !tc_aligned16(p.w) || !tc_aligned16(p.c)) return TC_EALIGN;
-  }
-  if (p.residual && !tc_aligned16(p.residual)) return TC_EALIGN;
-  if ((p.k & 7) || (p.lda & 7) || (p.ldw & 7) || (p.n & 7)) return TC_EALIGN;
-  if (p.out_f32 ? (p.ldc & 3) : (p.ldc & 7)) return TC_EALIGN;
-  if (p.residual && (p.ldr & 7)) return TC_EALIGN;
-  if (p.bias && (reinterpret_cast<uintptr_t>(p.bias) & 15u)) return TC_EALIGN;
-  if (p.row_bias && ((reinterpret_cast<uintptr_t>(p.row_bias) & 15u) || (p.ldrb & 3))) return TC_EALIGN;
-  if (p.ldw < p.k || p.ldc < p.n || (p.residual && p.ldr < p.n) || p.lda < p.cin) return TC_ESHAPE;
-  if (p.row_bias && (p.row_div <= 0 || p.ldrb < p.n)) return TC_EINVAL;
-  if (p.act < TC_ACT_NONE || p.act >= TC_ACT_GEGLU) return TC_EINVAL;
-  if (p.gather != TC_GATHER_CONV3x3 && p.gather != TC_GATHER_CONVT3) return TC_ESHAPE;
-  if (p.cin <= 0 || p.frames <= 0 || p.h_out <= 0 || p.w_out <= 0) return TC_ESHAPE;
-  if ((int64_t)p.frames * p.h_out * p.w_out != p.m) return TC_ESHAPE;
-  if (p.workspace || p.gn_part || p.a_norm) return TC_ESHAPE;
-  if (!tc_gemm_offsets_fit(p)) return TC_ESHAPE;
-  return TC_OK;
-}
-
-extern "C" int tc_conv_gn_eligible(const TcGemmParams* pp, int32_t gn_rows) {
-  if (!pp || conv_gn_check(*pp, false) != TC_OK) return 0;
-  static const float dummy = 0.f;
-  return conv_halo_launch(*pp, pp->batch > 0 ? pp->batch : 1, nullptr, true, ChGn{&dummy, gn_rows, 1});
-}
-
-extern "C" int tc_conv_gn_bf16(const TcGemmParams* pp, const float* scale_shift, int32_t gn_rows, int32_t silu, void* stream) {
-  if (!pp || !scale_shift) return TC_EINVAL;
-  if (!tc_aligned16(scale_shift)) return TC_EALIGN;
-  const int rc = conv_gn_check(*pp, true);
-  if (rc != TC_OK) return rc;
-  if (!conv_halo_launch(*pp, pp->batch > 0 ? pp->batch : 1, reinterpret_cast<hipStream_t>(stream), false,
-                        ChGn{scale_shift, gn_rows, silu ? 1 : 0})) return TC_ESHAPE;
-  TC_LAUNCH_CHECK();
-  return TC_OK;
 }

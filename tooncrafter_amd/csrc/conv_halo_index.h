@@ -135,15 +135,6 @@ CHX_HD bool w_pass_live(int i, int wave) {                   // the tall block's
 // ---- epilogue: tile row 16 y + x (y = 5 wm + i, x = lr) -> output row
 CHX_HD int64_t out_row(const Patch& t, int wm, int i, int lr) { return t.m00 + (int64_t)(wm * 5 + i) * t.ys + (int64_t)lr * t.xs; }
 
-// ---- GroupNorm prologue (ABI 10): float offset into the table [samples][2][cin] of the scale of channel (chunk 0, segment
-// tid & 7, element 0) for this patch's sample; + chunk * BK for later chunks, + cin for the shift row.  A thread's halo
-// vectors all carry segment tid & 7 (THREADS is a multiple of 8), so one 8 + 8 floats per chunk serve all of them.
-template <int GATHER>
-CHX_HD int64_t gn_table_offset(const Patch& t, int h, int w, int gn_rows, int cin, int tid) {
-  const int64_t any_row = GATHER == GATHER_3x3 ? (int64_t)t.img * h * w : (int64_t)t.img * 16 * h * w;   // a row of the patch's sample
-  return (any_row / gn_rows) * 2 * cin + (tid & 7) * 8;
-}
-
 // ---- K loop order: step kb of a group = (chunk c0 + c, tap); W columns of the step
 CHX_HD int w_k0(int tap, int chunk, int cin) { return tap * cin + chunk * BK; }
 

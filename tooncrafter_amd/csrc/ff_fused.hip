@@ -450,26 +450,35 @@ extern "C" int tc_ff_geglu_fused(const TcFfParams* p, void* stream) {
   a.w2 = reinterpret_cast<const bf16_t*>(p->w2); a.b2 = p->b2; a.out = reinterpret_cast<bf16_t*>(p->out);
   a.m = p->m; a.ldx = p->ldx; a.ldo = p->ldo; a.ln = p->ln ? 1 : 0; a.eps = p->ln_eps;
   a.tiles = (p->m + FF_BM - 1) / FF_BM;
+#ifdef TC_TIMING_BUILDS      /* interval trace / timing ablations: WRONG results by construction, never in the product library */
   a.trace = [&]() -> unsigned long long* { const char* e = getenv("TC_FF_TRACE"); return e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0)) : nullptr; }();
+#else
+  a.trace = nullptr;
+#endif
   static const int cus = [] { int d = 0, n = 256; if (hipGetDevice(&d) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
   const int gmax = [&] { const char* e = getenv("TC_FF_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : cus; }();
   // every block the same number of tiles: 640 tiles on 256 CUs are three rounds either way, and 214 blocks of three
   // leave the weight stream (L2 -> LDS, shared by all) less contended than 256 blocks of two or three
   const int rounds = (a.tiles + gmax - 1) / gmax;
   const int grid = (a.tiles + rounds - 1) / rounds;
+#ifdef TC_TIMING_BUILDS
   const int abl = [&] { const char* e = getenv("TC_FF_ABLATE"); return e ? atoi(e) : 0; }();
+#endif
   const int gi = [&] { const char* e = getenv("TC_FF_GILP"); return e ? atoi(e) : 8; }();
   const int la = [&] { const char* e = getenv("TC_FF_LOOKAHEAD"); return e ? atoi(e) : 3; }();
   const dim3 g((unsigned)grid), b(FF_THREADS);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define FF_LAUNCH(LA_, ABL_) hipLaunchKernelGGL((ff_fused_kernel<LA_, ABL_, 2>), g, b, 0, st, a)
+#ifdef TC_TIMING_BUILDS
   if (abl == 1) FF_LAUNCH(3, 1);
   else if (abl == 2) FF_LAUNCH(3, 2);
   else if (abl == 3) FF_LAUNCH(3, 3);
   else if (abl == 12) FF_LAUNCH(3, 12);
   else if (abl == 15) FF_LAUNCH(3, 15);
   else if (abl == 16 && a.trace) FF_LAUNCH(3, 16);
-  else if (gi == 2) FF_LAUNCH(3, 0);
+  else
+#endif
+  if (gi == 2) FF_LAUNCH(3, 0);
   else if (la == 2) FF_LAUNCH(2, 0);
   else if (la == 4) hipLaunchKernelGGL((ff_fused_kernel<4, 0, 8>), g, b, 0, st, a);
   else hipLaunchKernelGGL((ff_fused_kernel<3, 0, 8>), g, b, 0, st, a);       // the product kernel

@@ -481,6 +481,7 @@ int tc_gemm_tile16_try(const TcGemmParams& p, int batch, hipStream_t s, bool dry
   // TC_GEMM_PIPE = 2 only: on this tile the deeper prefetch measured 0.97-1.02x (profiles/r03_pipe_bench.txt) -- two
   // blocks of 80 KiB per CU already overlap each other's load latency -- so the default keeps the plain loop
   const bool pipe = [] { const char* e = getenv("TC_GEMM_PIPE"); return e && e[0] == '2'; }();      // per call (A/B runs)
+#ifdef TC_TIMING_BUILDS      /* timing ablations: WRONG results by construction, never in the product library */
   const int abl = [] { const char* e = getenv("TC_G16_ABLATE"); return e ? atoi(e) : 0; }();             // per call (timing runs)
   if (abl >= 1 && abl <= 4 && p.gather == TC_GATHER_CONV3x3 && !stats) {
     if (abl == 1) hipLaunchKernelGGL((gemm16_kernel<TC_GATHER_CONV3x3, false, false, 1>), grid, block, 0, s, p, order);
@@ -489,6 +490,7 @@ int tc_gemm_tile16_try(const TcGemmParams& p, int batch, hipStream_t s, bool dry
     if (abl == 4) hipLaunchKernelGGL((gemm16_kernel<TC_GATHER_CONV3x3, false, false, 4>), grid, block, 0, s, p, order);
     return 1;
   }
+#endif
   // TC_G16_ILV: requests between the MFMAs (see the kernel header).  Unset = loop 2 for the convolutions, the plain loop
   // for linear problems (measured, profiles/r04_g16_tall_ilv_bench.txt: 3x3 / temporal convolutions 1.01-1.03x on the
   // 160-row tile, linear 0.98-1.02x; inside the UNet 8.29 / 8.30 against 8.27 / 8.28 frames/s, alternating on one lease:

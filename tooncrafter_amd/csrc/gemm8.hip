@@ -507,6 +507,7 @@ int tc_gemm8_try(const TcGemmParams& p, int batch, hipStream_t s, bool dry) {
   dim3 grid((unsigned)g, 1, (unsigned)batch), block(G8_THREADS);
   const int tt = (int)total;
   const int stg = [] { const char* e = getenv("TC_G8_STAGGER"); return e ? atoi(e) : 0; }();
+#ifdef TC_TIMING_BUILDS      /* timing ablations: WRONG results by construction, never in the product library */
   const int ab = [] { const char* e = getenv("TC_G8_ABLATE"); return e ? atoi(e) : 0; }();
   if (ab && p.gather == TC_GATHER_LINEAR) {
 #define TC_G8_AB(X) case X: hipLaunchKernelGGL((gemm8_kernel<TC_GATHER_LINEAR, X>), grid, block, 0, s, p, tt, stg); return 1
@@ -516,6 +517,7 @@ int tc_gemm8_try(const TcGemmParams& p, int batch, hipStream_t s, bool dry) {
     }
 #undef TC_G8_AB
   }
+#endif
   switch (p.gather) {
     case TC_GATHER_LINEAR: hipLaunchKernelGGL((gemm8_kernel<TC_GATHER_LINEAR>), grid, block, 0, s, p, tt, stg); break;
     case TC_GATHER_CONV3x3: hipLaunchKernelGGL((gemm8_kernel<TC_GATHER_CONV3x3>), grid, block, 0, s, p, tt, stg); break;

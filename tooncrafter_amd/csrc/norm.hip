@@ -21,7 +21,6 @@
 // Algorithmic traffic: read x twice, write y once (the second read mostly hits the 256 MiB
 // Infinity Cache for UNet-sized tensors).
 #include "common.h"
-#include "gn_route.h"
 
 #include <stdlib.h>
 
@@ -155,46 +154,6 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     if (var < 0.0) var = 0.0;
     stats[(int64_t)sg * 2] = (float)mean;
     stats[(int64_t)sg * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
-  }
-}
-
-// ABI 10 (tc_groupnorm_scale_shift): the statistics as what a CONSUMER applies -- part [samples][nchunks][32][2] ->
-// ss [samples][2][c]: scale[ch] = rstd(group) * gamma[ch], shift[ch] = beta[ch] - mean(group) * scale[ch] (gn_apply's
-// prologue, once per tensor instead of once per block).  One block per sample: its four waves reduce eight groups each over
-// the chunks (fp64, fixed order, as gn_finalize), then all threads walk the channels.
-__global__ __launch_bounds__(256) void gn_finalize_ss_kernel(const float* __restrict__ part, float* __restrict__ ss,
-                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             int rows, int c, int nchunks, float eps) {
-  __shared__ float st[32][2];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int sample = blockIdx.x;
-  const int cpg = c / 32;
-  for (int g = wave * 8; g < wave * 8 + 8; ++g) {
-    const float* pp = part + ((int64_t)sample * nchunks * 32 + g) * 2;
-    double a = 0.0, b = 0.0;
-    for (int k = lane; k < nchunks; k += 64) {
-      const float2 v = *reinterpret_cast<const float2*>(pp + (int64_t)k * 64);
-      a += v.x;
-      b += v.y;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
-    if (lane == 0) {
-      const double cnt = (double)rows * cpg;
-      const double mean = a / cnt;
-      double var = b / cnt - mean * mean;
-      if (var < 0.0) var = 0.0;
-      st[g][0] = (float)mean;
-      st[g][1] = (float)(1.0 / sqrt(var + (double)eps));
-    }
-  }
-  __syncthreads();
-  float* o = ss + (int64_t)sample * 2 * c;
-  for (int ch = tid; ch < c; ch += 256) {
-    const int g = ch / cpg;
-    const float a = st[g][1] * gamma[ch];
-    o[ch] = a;
-    o[c + ch] = beta[ch] - st[g][0] * a;
   }
 }
 
@@ -587,24 +546,35 @@ extern "C" int tc_groupnorm(const tc_bf16* x, tc_bf16* y, const float* gamma, co
   {
     // single-pass kernel when a (sample, unit) slab fits the registers of one block (TC_GN_ONEPASS=0: never)
     static const bool onepass = [] { const char* e = getenv("TC_GN_ONEPASS"); return !(e && e[0] == '0'); }();
-    const GnOnepass op = gn_onepass_rule(samples, rows, c);
-    const int u = op.u, vu = op.vu;
-    if (onepass && op.nv && tc_aligned16(gamma) && tc_aligned16(beta)) {
+    const int cpg = c / 32;
+    int u = cpg;
+    while (u % 8) u += cpg;                                       // lcm(8, cpg) = U channels per unit
+    const int vu = u / 8, gu = u / cpg;
+    if (onepass && (c % u) == 0 && gu <= 4 && vu <= 64 && tc_aligned16(gamma) && tc_aligned16(beta)) {
+      const int64_t nvec = (int64_t)rows * vu;
       const dim3 grid(c / u, samples);
       const bf16_t* xb = reinterpret_cast<const bf16_t*>(x);
       bf16_t* yb = reinterpret_cast<bf16_t*>(y);
+      auto fits = [&](int t, int nv) { return (int64_t)((rows + t / vu - 1) / (t / vu)) <= nv; };
       // measured (profiles/r02_gn_onepass_ab.txt): wins 13-32 % where the grid fills the chip (per-frame norms of levels
       // 1-3) or the tensor is tiny (level-3 clip-wide, 3 MB); LOSES with 64 blocks on a 13 MB tensor (level-2
       // clip-wide: 20 -> 31 us) and is neutral at level 0 (a 512-thread / 26-vector instance: dropped)
-      if (op.nv == 4) {
+      const int64_t nblk = (int64_t)(c / u) * samples;
+      const int64_t bytes = nvec * 16 * samples * (c / u);
+      bool done = nblk >= 128 || bytes <= (4 << 20);
+      if (!done) {}
+      else if (fits(256, 4)) {
         if (silu) hipLaunchKernelGGL((gn_onepass_kernel<256, 4, true>), grid, dim3(256), 0, s, xb, yb, gamma, beta, rows, c, vu, eps);
         else hipLaunchKernelGGL((gn_onepass_kernel<256, 4, false>), grid, dim3(256), 0, s, xb, yb, gamma, beta, rows, c, vu, eps);
-      } else {
+      } else if (fits(256, 13)) {
         if (silu) hipLaunchKernelGGL((gn_onepass_kernel<256, 13, true>), grid, dim3(256), 0, s, xb, yb, gamma, beta, rows, c, vu, eps);
         else hipLaunchKernelGGL((gn_onepass_kernel<256, 13, false>), grid, dim3(256), 0, s, xb, yb, gamma, beta, rows, c, vu, eps);
       }
-      TC_LAUNCH_CHECK();
-      return TC_OK;
+      else done = false;
+      if (done) {
+        TC_LAUNCH_CHECK();
+        return TC_OK;
+      }
     }
   }
   int nch, cr;
@@ -621,27 +591,6 @@ extern "C" int tc_groupnorm(const tc_bf16* x, tc_bf16* y, const float* gamma, co
                                reinterpret_cast<bf16_t*>(y), gamma, beta, stats, rows, c, cr);
   else hipLaunchKernelGGL(gn_apply_kernel<false>, grid, block, 0, s, reinterpret_cast<const bf16_t*>(x),
                           reinterpret_cast<bf16_t*>(y), gamma, beta, stats, rows, c, cr);
-  TC_LAUNCH_CHECK();
-  return TC_OK;
-}
-
-// ABI 10: GroupNorm's statistics pass alone, delivered as the per-(sample, channel) affine map its consumer applies
-// (tc_conv_gn_bf16 normalises its A operand with it: the apply pass and the normalised tensor disappear)
-extern "C" int tc_groupnorm_scale_shift(const tc_bf16* x, const float* gamma, const float* beta, int32_t samples, int32_t rows,
-                                        int32_t c, float eps, float* scale_shift, void* workspace, int64_t workspace_bytes,
-                                        void* stream) {
-  if (!x || !gamma || !beta || !scale_shift || !workspace || samples <= 0 || rows <= 0 || c <= 0) return TC_EINVAL;
-  if ((c % 32) != 0 || (c % 8) != 0 || c > GN_MAX_SLOTS * GN_THREADS * 8 || c > 4096 || samples > 65535) return TC_ESHAPE;
-  if (!tc_aligned16(x) || !tc_aligned16(scale_shift)) return TC_EALIGN;
-  if (workspace_bytes < tc_groupnorm_workspace(samples, rows, c)) return TC_EWORKSPACE;
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  int nch, cr;
-  gn_chunking(samples, rows, &nch, &cr);
-  float* part = reinterpret_cast<float*>(workspace);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(nch, samples), dim3(GN_THREADS), 0, s, reinterpret_cast<const bf16_t*>(x), part, rows, c,
-                     nch, cr);
-  TC_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_finalize_ss_kernel, dim3(samples), dim3(256), 0, s, part, scale_shift, gamma, beta, rows, c, nch, eps);
   TC_LAUNCH_CHECK();
   return TC_OK;
 }

@@ -515,15 +515,23 @@ extern "C" int tc_temporal_attn_fused(const TcTbParams* p, void* stream) {
   a.tiles_per_b = p->hw / 8;
   a.tiles = p->b * a.tiles_per_b;
   static const int cus = [] { int d = 0, n = 256; if (hipGetDevice(&d) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
+#ifdef TC_TIMING_BUILDS      /* timing ablations / interval trace: WRONG results by construction, never in the product library */
   a.abl = [&] { const char* e = getenv("TC_TB_ABLATE"); return e ? atoi(e) : 0; }();
   a.trace = [&]() -> unsigned long long* { const char* e = getenv("TC_TB_TRACE"); return e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0)) : nullptr; }();
   if (!a.trace) a.abl &= ~8;
+#else
+  a.abl = 0;
+  a.trace = nullptr;
+#endif
   a.stagger = [&] { const char* e = getenv("TC_TB_STAGGER"); return e ? atoi(e) : 0; }();
   const int gmax = [&] { const char* e = getenv("TC_TB_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : cus; }();
   const int rounds = (a.tiles + gmax - 1) / gmax;
   const int grid = (a.tiles + rounds - 1) / rounds;
+#ifdef TC_TIMING_BUILDS
   if (a.abl & 8) hipLaunchKernelGGL(tb_fused_kernel<true>, dim3((unsigned)grid), dim3(TB_THREADS), 0, reinterpret_cast<hipStream_t>(stream), a);
-  else hipLaunchKernelGGL(tb_fused_kernel<false>, dim3((unsigned)grid), dim3(TB_THREADS), 0, reinterpret_cast<hipStream_t>(stream), a);
+  else
+#endif
+  hipLaunchKernelGGL(tb_fused_kernel<false>, dim3((unsigned)grid), dim3(TB_THREADS), 0, reinterpret_cast<hipStream_t>(stream), a);
   TC_LAUNCH_CHECK();
   return TC_OK;
 }

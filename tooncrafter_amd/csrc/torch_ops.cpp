@@ -14,11 +14,6 @@
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
-#include <hip/hip_runtime_api.h>
-#include <stdlib.h>
-
-#include <map>
-#include <mutex>
 #include <tuple>
 #include <vector>
 
@@ -217,44 +212,12 @@ void check_affine(const Tensor& g, const Tensor& b, int64_t c, const char* what)
               g.is_contiguous() && b.is_contiguous() && g.numel() == c && b.numel() == c, what, ": gamma / beta must be contiguous fp32 CUDA [C]");
 }
 
-// the cooperative GroupNorm's counters: zero before first use, left zero by the kernel (see include/tooncrafter_hip.h, ABI 11)
-Tensor gn_sync_for(const Tensor& x) {
-  static std::mutex mu;
-  static std::map<int, Tensor> bufs;
-  std::lock_guard<std::mutex> lock(mu);
-  const int dev = x.get_device();
-  auto it = bufs.find(dev);
-  if (it == bufs.end()) {
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(c10::hip::getCurrentHIPStream().stream(), &cap);
-    TORCH_CHECK(cap == hipStreamCaptureStatusNone,
-                "groupnorm: first use of the cooperative kernel inside a stream capture -- run the operator once eagerly first");
-    it = bufs.emplace(dev, at::zeros({65536 * 4}, x.options().dtype(at::kInt))).first;
-  }
-  return it->second;
-}
-
-bool gn_coop_allowed() {        // as ops.HipOps: never while the guided passes run on their own streams
-  const char* e = getenv("TC_CFG_STREAMS");
-  return !(e && e[0] == '1');
-}
-
 Tensor groupnorm_cuda(const Tensor& x, const Tensor& gamma, const Tensor& beta, int64_t samples, int64_t rows, double eps, bool silu) {
   check_rows(x, "groupnorm: x");
   const int64_t c = x.size(1);
   TORCH_CHECK(x.is_contiguous() && x.size(0) == samples * rows, "groupnorm: x must be contiguous [samples*rows, C]");
   check_affine(gamma, beta, c, "groupnorm");
   Tensor y = at::empty_like(x);
-  if (gn_coop_allowed() && tc_groupnorm_coop_grid((int32_t)samples, (int32_t)rows, (int32_t)c) > 0) {
-    // ABI 11: one launch, x read once (csrc/gn_coop.hip); the zeroed counter buffer lives per device for the process' lifetime
-    Tensor sync = gn_sync_for(x);
-    const int64_t nb = tc_groupnorm_coop_workspace((int32_t)samples, (int32_t)rows, (int32_t)c);
-    Tensor cws = at::empty({nb > 16 ? nb : 16}, x.options().dtype(at::kByte));
-    check_rc(tc_groupnorm_coop(bf(x), reinterpret_cast<tc_bf16*>(y.data_ptr()), gamma.data_ptr<float>(), beta.data_ptr<float>(),
-                               (int32_t)samples, (int32_t)rows, (int32_t)c, (float)eps, silu ? 1 : 0, cws.data_ptr(), nb,
-                               sync.data_ptr(), sync.numel() * 4, cur_stream()), "tc_groupnorm_coop");
-    return y;
-  }
   const int64_t nbytes = tc_groupnorm_workspace((int32_t)samples, (int32_t)rows, (int32_t)c);
   Tensor ws = at::empty({nbytes > 16 ? nbytes : 16}, x.options().dtype(at::kByte));
   check_rc(tc_groupnorm(bf(x), reinterpret_cast<tc_bf16*>(y.data_ptr()), gamma.data_ptr<float>(), beta.data_ptr<float>(),

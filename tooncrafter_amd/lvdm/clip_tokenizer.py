@@ -6,11 +6,14 @@ published algorithm (open_clip/tokenizer.py: SimpleTokenizer + tokenize, itself 
 byte -> unicode alphabet, whitespace / HTML clean-up, lower-casing, the `<start_of_text>` / `<end_of_text>` specials, a
 regex pre-tokeniser and rank-ordered BPE merges, context length 77 with truncation that keeps the end token.
 
-**Parity unpinned**: neither the package nor its vocabulary file (`bpe_simple_vocab_16e6.txt.gz`, 1.3 MB, shipped inside
-open_clip) exists here, so no golden can be made.  The merges are data, not code: pass the path of that file
-(`CLIPTokenizer(path)`, or `TC_CLIP_BPE_VOCAB`); without it only the empty prompt -- the interpolation scripts' default --
-can be tokenised (its tokens do not depend on the vocabulary).  open_clip also runs `ftfy.fix_text` on the input when
-ftfy is installed; ftfy is absent here and plain ASCII prompts are unaffected by it.
+**Parity**: pinned (round 5) to an independent implementation of the same tokeniser -- transformers.CLIPTokenizer, the Rust
+`tokenizers` BPE -- on a merge table both are given (tests/golden/make_openclip_golden.py -> clip_bpe_hf.json;
+tests/test_openclip_golden_cpu.py: case folding, whitespace, contractions, digits, punctuation runs, non-ASCII letters,
+truncation).  NOT pinned: open_clip's real vocabulary file (`bpe_simple_vocab_16e6.txt.gz`, 1.3 MB, shipped inside open_clip) --
+neither the package nor the file exists here.  The merges are data, not code: pass the path of that file (`CLIPTokenizer(path)`,
+or `TC_CLIP_BPE_VOCAB`); without it only the empty prompt -- the interpolation scripts' default -- can be tokenised (its tokens
+do not depend on the vocabulary).  open_clip also runs `ftfy.fix_text` on the input when ftfy is installed; ftfy is absent here
+and plain ASCII prompts are unaffected by it.
 """
 from __future__ import annotations
 

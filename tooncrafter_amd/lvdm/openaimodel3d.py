@@ -105,7 +105,7 @@ class TemporalConvBlock(PackedModule):
         pk = self.pk
         y = act.rows
         geom = dict(kind="t3", frames=act.frames, t_len=act.t, cin=act.c, h_out=act.h, w_out=act.w)
-        # GroupNorm + SiLU + convolution as ONE operator (ops.gn_conv): two launches as before, or -- TC_GN_FUSE=1, ABI 10 -- a
+        # GroupNorm + SiLU + convolution as ONE host operator (ops.gn_conv): two launches; round 5 measured the fused alternative -- a
         # statistics pass and a convolution that normalises its own operand
         gn = dict(samples=act.b, rows=act.t * act.hw, eps=1e-5, silu=True, conv=geom)
         for i in range(1, 5):

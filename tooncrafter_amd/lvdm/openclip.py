@@ -7,7 +7,8 @@ rebuilds those two module trees with open_clip's parameter names -- so the `cond
 `embedder.model.*` tensors of a ToonCrafter checkpoint load strictly -- and runs them on the same kernels as
 the UNet: LayerNorm, tc_gemm_bf16 (bias / exact-erf GELU / residual epilogues), and attention as
 GEMM -> row softmax -> GEMM (tc_softmax_rows with K padding and the causal text mask), because the vision
-tower's head dimension is 80, not 64.  PARITY UNPINNED (see oracle/openclip.py): no golden vectors exist.
+tower's head dimension is 80, not 64.  Parity: pinned to HuggingFace transformers' CLIP at the ViT-H/14 geometry
+(tests/golden/make_openclip_golden.py; tests/test_openclip_golden_cpu.py for the oracle, test_gpu_models.py for this path).
 
 Result-preserving restructurings: the patch-embedding convolution (kernel = stride = 14) is a GEMM over
 unfolded patches with the positional embedding as its residual; V's bias is folded into the out-projection

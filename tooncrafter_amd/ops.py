@@ -112,14 +112,6 @@ class HipOps:
         # 6.08 -> 5.72 on a slow lease) and the producing convolutions gain 0.4-1.1 ms (their epilogues fold 160 rows per
         # column and end on two block barriers): 7.79 vs 7.79 frames/s on one lease, 6.63 vs 6.75 on the other
         self.gn_part = os.environ.get("TC_GN_PART", "0") == "1"
-        # ABI 10: GroupNorm(+SiLU) applied inside the convolution that consumes it (gn_conv -> tc_groupnorm_scale_shift +
-        # tc_conv_gn_bf16, csrc/conv_halo.hip).  OFF by default: the kernel was written without GPU access
-        self.gn_fuse = os.environ.get("TC_GN_FUSE", "0") == "1"
-        # ABI 11: cooperative single-launch GroupNorm (csrc/gn_coop.hip).  Its blocks wait for each other, so two such launches
-        # must never run concurrently on two streams: off when the guided passes run on their own streams (TC_CFG_STREAMS=1)
-        self.gn_coop = os.environ.get("TC_CFG_STREAMS", "0") != "1"
-        self._gn_sync_buf = {}
-        self.gn_fuse_calls = {"fused": 0, "separate": 0}
 
     # ------------------------------------------------------------------ workspace
     def _workspace(self, nbytes: int, device) -> torch.Tensor:
@@ -129,11 +121,8 @@ class HipOps:
     # ------------------------------------------------------------------ GEMM family
     def gemm(self, a, w, bias=None, *, act=ACT_NONE, residual=None, row_bias=None, row_div=0,
              alpha=1.0, out_scale=1.0, out=None, out_f32=False, conv=None, batch=1,
-             stride_a=0, stride_w=0, stride_c=0, m=None, a_norm_eps=None, gn_stats=False, _gn=None):
+             stride_a=0, stride_w=0, stride_c=0, m=None, a_norm_eps=None, gn_stats=False):
         """out[M, N'] = act(alpha * gather(a) @ w^T + bias + row_bias[m // row_div]) * out_scale + residual.
-
-        _gn (ABI 10, set by gn_conv only): (scale_shift, gn_rows, silu) -- the convolution normalises its A operand itself
-        (tc_conv_gn_bf16); `a` is then the UN-normalised tensor.
 
         gn_stats (ABI 9): the result is (out, GnPart | None) -- when the kernel this problem runs on can emit them
         (tc_gemm_gn_rows), per-row-block column sums of the rounded outputs, which `groupnorm(..., part=)` takes instead
@@ -220,10 +209,6 @@ class HipOps:
                 raise ValueError("gemm: a_norm_eps and the MXFP8 route exclude each other")
             if not self.lib.tc_gemm_ws_eligible(C.byref(p)):
                 raise ValueError("gemm: a_norm_eps needs a problem the weight-stationary kernel takes (gemm_ln_eligible)")
-        if _gn is not None:
-            ss, gn_rows, silu = _gn
-            _lib.check(self.lib.tc_conv_gn_bf16(C.byref(p), ss.data_ptr(), int(gn_rows), 1 if silu else 0, _stream()), "tc_conv_gn_bf16")
-            return (out, None) if gn_stats else out
         if self.fp8 is not None:
             if self._fp8_eligible(p, conv is not None, n_out, batch):
                 self.fp8_calls["mx"] += 1
@@ -453,19 +438,6 @@ class HipOps:
         return out
 
     # ------------------------------------------------------------------ norms
-    def _gn_sync(self, device):
-        """The cooperative GroupNorm's counters (zero before the first call; the kernel leaves them zero): one buffer per
-        device for the process' lifetime.  Must exist before a hipGraph capture starts (a captured allocation would live in
-        the graph's private pool): the models run one eager forward before they capture, which creates it."""
-        key = device.index if device.index is not None else torch.cuda.current_device()
-        buf = self._gn_sync_buf.get(key)
-        if buf is None:
-            if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError("groupnorm: first use of the cooperative kernel inside a stream capture -- run the "
-                                   "operator once eagerly first (its counter buffer must not be a captured allocation)")
-            buf = self._gn_sync_buf[key] = torch.zeros(65536 * 4, dtype=torch.int32, device=device)
-        return buf
-
     def groupnorm(self, x, gamma, beta, *, samples, rows, eps, silu=False, part=None):
         """x: contiguous [samples*rows, C]; statistics over (rows, C/32) per (sample, group).  `part` (a GnPart from
         the gemm that produced x, or None): statistics from the producer's partial sums -- one pass over x, not two."""
@@ -485,62 +457,16 @@ class HipOps:
                                                   rows, c, float(eps), 1 if silu else 0, ws.data_ptr(), nbytes, _stream()),
                        "tc_groupnorm_part")
             return y
-        if self.gn_coop and self.lib.tc_groupnorm_coop_grid(samples, rows, c) > 0:
-            sync = self._gn_sync(x.device)
-            nb = self.lib.tc_groupnorm_coop_workspace(samples, rows, c)
-            ws = self._workspace(nb, x.device)
-            _lib.check(self.lib.tc_groupnorm_coop(x.data_ptr(), y.data_ptr(), gp, bp, samples, rows, c, float(eps),
-                                                  1 if silu else 0, ws.data_ptr(), nb, sync.data_ptr(), sync.numel() * 4,
-                                                  _stream()), "tc_groupnorm_coop")
-            return y
         _lib.check(self.lib.tc_groupnorm(x.data_ptr(), y.data_ptr(), gp, bp, samples,
                                          rows, c, float(eps), 1 if silu else 0, ws.data_ptr(), nbytes, _stream()),
                    "tc_groupnorm")
         return y
 
-    # ------------------------------------------------------------------ GroupNorm inside its convolution (ABI 10)
-    def groupnorm_scale_shift(self, x, gamma, beta, *, samples, rows, eps):
-        """GroupNorm's statistics pass alone: fp32 [samples, 2, C] = per (sample, channel) scale = rstd * gamma and
-        shift = beta - mean * scale -- what `gemm(..., _gn=)` applies to its A operand."""
-        x = _rows_view(x)
-        c = x.shape[1]
-        if not x.is_contiguous() or x.shape[0] != samples * rows or gamma.numel() != c or beta.numel() != c:
-            raise ValueError("groupnorm_scale_shift: x must be contiguous [samples*rows, C], gamma / beta [C]")
-        gp, bp = _dev(gamma, torch.float32, "groupnorm: gamma"), _dev(beta, torch.float32, "groupnorm: beta")
-        ss = torch.empty((samples, 2, c), dtype=torch.float32, device=x.device)
-        nbytes = self.lib.tc_groupnorm_workspace(samples, rows, c)
-        ws = self._workspace(nbytes, x.device)
-        _lib.check(self.lib.tc_groupnorm_scale_shift(x.data_ptr(), gp, bp, samples, rows, c, float(eps), ss.data_ptr(),
-                                                     ws.data_ptr(), nbytes, _stream()), "tc_groupnorm_scale_shift")
-        return ss
-
-    def gn_conv_eligible(self, x, w, conv, gn_rows) -> bool:
-        """Would `gn_conv` take the one-pass route for this problem?  The library's own rule (tc_conv_gn_eligible: the
-        tap-reuse kernel's shapes, one GroupNorm sample per patch); never on the MXFP8 route; TC_GN_FUSE=1 only."""
-        if not self.gn_fuse or self.fp8 is not None or conv is None or not x.is_contiguous() or x.shape[1] != conv["cin"]:
-            return False
-        p = TcGemmParams()
-        kind = conv["kind"]
-        p.gather = GATHER_CONV3x3 if kind == "3x3" else GATHER_CONVT3
-        p.cin, p.frames, p.t_len = conv["cin"], conv["frames"], conv.get("t_len", 1)
-        p.h_out, p.w_out = conv["h_out"], conv["w_out"]
-        p.h_in, p.w_in = conv.get("h_in", conv["h_out"]), conv.get("w_in", conv["w_out"])
-        p.stride, p.upsample, p.pad = conv.get("stride", 1), 1 if conv.get("upsample", False) else 0, conv.get("pad", 1)
-        p.m, p.n, p.k = p.frames * p.h_out * p.w_out, w.shape[0], w.shape[1]
-        p.lda, p.ldw, p.ldc, p.ldr, p.ldrb = x.stride(0), w.stride(0), w.shape[0], w.shape[0], w.shape[0]
-        p.row_div, p.alpha, p.out_scale, p.batch = 1, 1.0, 1.0, 1
-        return bool(self.lib.tc_conv_gn_eligible(C.byref(p), int(gn_rows)))
-
     def gn_conv(self, x, gamma, beta, w, bias=None, *, samples, rows, eps, conv, silu=True, part=None, **kw):
-        """conv(act(GroupNorm(x))) with the epilogue of `gemm` (**kw: row_bias / row_div / residual / act / gn_stats / out_f32).
-        The reference's pair lvdm/basics.py:76-87 -> nn.Conv2d / nn.Conv3d (openaimodel3d.py:154,179,255-266).  With
-        TC_GN_FUSE=1 and an eligible problem: ONE statistics pass + the convolution that normalises its own operand (the
-        normalised tensor is never written); otherwise the two operators as before (`part`: see groupnorm)."""
-        if self.gn_conv_eligible(x, w, conv, rows):
-            self.gn_fuse_calls["fused"] += 1
-            ss = self.groupnorm_scale_shift(x, gamma, beta, samples=samples, rows=rows, eps=eps)
-            return self.gemm(x, w, bias, conv=conv, _gn=(ss, rows, silu), **kw)
-        self.gn_fuse_calls["separate"] += 1
+        """conv(act(GroupNorm(x))) with the epilogue of `gemm` (**kw: row_bias / row_div / residual / act / gn_stats / out_f32):
+        the reference's pair lvdm/basics.py:76-87 -> nn.Conv2d / nn.Conv3d (openaimodel3d.py:154,179,255-266) as ONE host
+        operator, two launches.  (Round 5 measured the alternative -- the convolution normalising its own operand, ABI 10 --
+        at -4 % per clip and removed it: DESIGN.md 5.6.)  `part`: see groupnorm."""
         h = self.groupnorm(x, gamma, beta, samples=samples, rows=rows, eps=eps, silu=silu, part=part)
         return self.gemm(h, w, bias, conv=conv, **kw)
 

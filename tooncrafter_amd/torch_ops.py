@@ -56,14 +56,15 @@ class TorchLibOps(HipOps):
 
     def gemm(self, a, w, bias=None, *, act=ACT_NONE, residual=None, row_bias=None, row_div=0, alpha=1.0, out_scale=1.0,
              out=None, out_f32=False, conv=None, batch=1, stride_a=0, stride_w=0, stride_c=0, m=None, a_norm_eps=None,
-             gn_stats=False, _gn=None):
-        # fp8 routing, the ABI 9 producer statistics (a second result) and the ABI 10 GroupNorm prologue live in HipOps.gemm
-        if out is not None or batch != 1 or m is not None or self.fp8 is not None or gn_stats or _gn is not None:
+             gn_stats=False):
+        # fp8 routing and the ABI 9 producer statistics (a second result; only when TC_GN_PART=1 can produce them) live in HipOps.gemm
+        if out is not None or batch != 1 or m is not None or self.fp8 is not None or (gn_stats and self.gn_part):
             return super().gemm(a, w, bias, act=act, residual=residual, row_bias=row_bias, row_div=row_div, alpha=alpha,
                                 out_scale=out_scale, out=out, out_f32=out_f32, conv=conv, batch=batch, stride_a=stride_a,
-                                stride_w=stride_w, stride_c=stride_c, m=m, a_norm_eps=a_norm_eps, gn_stats=gn_stats, _gn=_gn)
-        return self.t.gemm(a, w, bias, residual, row_bias, int(row_div), int(act), float(alpha), float(out_scale),
-                           bool(out_f32), conv_list(conv), -1.0 if a_norm_eps is None else float(a_norm_eps))
+                                stride_w=stride_w, stride_c=stride_c, m=m, a_norm_eps=a_norm_eps, gn_stats=gn_stats)
+        res = self.t.gemm(a, w, bias, residual, row_bias, int(row_div), int(act), float(alpha), float(out_scale),
+                          bool(out_f32), conv_list(conv), -1.0 if a_norm_eps is None else float(a_norm_eps))
+        return (res, None) if gn_stats else res                 # ResBlock / TemporalConvBlock always ask; no producer statistics here
 
     def quant_mxfp8(self, x, k=None):
         return self.t.quant_mxfp8(x, int(x.shape[1] if k is None else k))
