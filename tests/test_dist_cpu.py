@@ -78,6 +78,25 @@ def test_bench_launches_its_own_ranks():
     assert json.loads(lines[0]) == {"selftest": "launcher", "n_gpus": 2, "gathered": [0.0, 1.0]}
 
 
+def test_bench_launches_eight_ranks():
+    """The first real 8-GPU lease must not also be the first 8-rank rendezvous: `python bench.py --gpus 8
+    --launcher-selftest` (world 8 over gloo on this CPU box) -- torch.distributed.run on 127.0.0.1, eight ranks, the one
+    gather to rank 0 (reference scripts/evaluation/ddp_wrapper.py:8-47, inference.py:314-320: clips sharded, no data-path
+    collective but the final gather), ONE JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--launcher-selftest"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    assert json.loads(lines[0]) == {"selftest": "launcher", "n_gpus": 8, "gathered": [float(r) for r in range(8)]}
+
+
 def test_gather_world2_gloo():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

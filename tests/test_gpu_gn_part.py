@@ -29,6 +29,14 @@ def hip():
     return h
 
 
+@pytest.fixture(autouse=True)
+def _implicit_gemm_convolutions(monkeypatch):
+    """Producer statistics come from the implicit-GEMM kernels' epilogues; the tap-reuse kernel that takes the UNet's 3x3
+    convolutions by default (csrc/conv_halo.hip) emits none (tc_gemm_gn_rows says 0 there).  These tests are about the
+    emitting kernels, so the 3x3 convolutions are kept on them."""
+    monkeypatch.setenv("TC_CONV_HALO", "0")
+
+
 @pytest.fixture(scope="module")
 def emu():
     return EmuOps(round_bf16=True)
