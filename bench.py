@@ -373,7 +373,7 @@ CALIB_REFERENCE = {"matmul_8192_bf16_tflops": 1300.0, "copy_1gib_gbs": 2000.0}
 def lease_calibration(device):
     """What THIS lease delivers on two fixed yardsticks, measured in-process right where it is called (bench.py calls it
     before and after the timed region): (i) a hipBLASLt 8192^3 bf16 product (torch.matmul -- calibration only, never on the
-    product path), (ii) a 1 GiB device-to-device copy.  Leases of this pool differ by +-12 % on the same binary (DESIGN.md
+    product path), (ii) a 1 GiB device-to-device copy.  Leases of this pool differ by +-12 % on the same binary (docs/LAB_NOTEBOOK.md
     5.2, 5.5); these two numbers travel with the headline so that rounds can be compared: `value_normalised` =
     value x (reference matmul rate / measured matmul rate), the reference being a fixed constant (CALIB_REFERENCE)."""
     a = torch.empty((8192, 8192), device=device, dtype=torch.bfloat16).normal_()

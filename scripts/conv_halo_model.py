@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Index-level model of the tap-reuse 3x3 convolution planned in DESIGN.md section 8 (item 1), in numpy.
+"""Index-level model of the tap-reuse 3x3 convolution planned in docs/LAB_NOTEBOOK.md section 8 (item 1), in numpy.
 
 It moves data exactly the way the kernel will -- 2-D output tiles of TH x TW pixels, one halo tile of
 (TH+2) x (TW+2) pixels per 64-channel chunk brought into an LDS image by 1-KiB DMA pieces of 8 pixels

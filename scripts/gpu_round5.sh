@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round-5 GPU visits.  usage: scripts/gpu_round5.sh TAG stage...     (everything under its own `timeout`)
+# Round-5 GPU visits, as PLANNED at the end of round 4 (the visits that were actually made: scripts/gpu_r5_call1.sh .. call4.sh;
+# the `unver` gate is gone: those tests are part of the default -m gpu run now).  usage: scripts/gpu_round5.sh TAG stage...     (everything under its own `timeout`)
 #   unver   : the GATED tests of kernels written without a GPU (conv_halo.hip) -- run FIRST, alone, short timeout
 #   halo    : kernel-level A/B of TC_CONV_HALO on the UNet's convolution shapes
 #   haloclip: clip-level A/B (alternating) of TC_CONV_HALO=1 against the default routing
@@ -16,7 +17,7 @@ REPO=$(pwd)
 for s in "$@"; do
   t0=$(date +%s)
   case $s in
-    unver)   TC_TEST_UNVERIFIED=1 timeout 300 python -m pytest tests/test_gpu_conv_halo.py -m gpu -x -q -p no:cacheprovider > $OUT/pytest_unverified.log 2>&1 ;;
+    unver)   timeout 300 python -m pytest tests/test_gpu_conv_halo.py -m gpu -x -q -p no:cacheprovider > $OUT/pytest_unverified.log 2>&1 ;;
     halo)    timeout 300 python scripts/conv_halo_bench.py > $OUT/conv_halo_bench.txt 2>&1 ;;
     haloclip) (for v in 0 1 0 1; do echo "== TC_CONV_HALO=$v"; TC_CONV_HALO=$v timeout 300 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['stage_ms_per_clip'])"; done) > $OUT/conv_halo_clip_ab.txt 2>&1 ;;
     gn)      timeout 300 python scripts/norm_bench.py > $OUT/norm_bench.txt 2>&1 ;;

@@ -2,7 +2,7 @@
 """Workload for rocprofv3 --pmc passes: the level-0 3x3 convolution (81920 x 320 x 2880) on the default routing (gemm16) and on
 the halo-patch kernel (160-row and tall), three launches each -- separate kernels, so the counters come out per variant.
 What to read (scripts/pmc_halo.sh, third pass): TCP_TCC_READ_REQ (L2 requests from the CUs), TCC_HIT / TCC_MISS -- the
-prediction of DESIGN.md 5.5 (11) is that the halo kernel removes most of A's L2 misses, not just its requests."""
+prediction of docs/LAB_NOTEBOOK.md 5.5 (11) is that the halo kernel removes most of A's L2 misses, not just its requests."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -69,6 +69,16 @@ def test_torch_ops_match_ctypes_binding_bitwise(both):
         c.fp8 = None
     with pytest.raises(RuntimeError):
         t.gemm(a[:, :60], w[:, :60].contiguous())                  # K not a multiple of 8: the C ABI's TC_EALIGN surfaces
+    # the level-0 one-launch operators (ABI 9) through the op layer: same launches, same bits
+    x0 = rnd(2 * 16 * 40, 320, seed=20)
+    w1, b1 = pack_geglu(torch.randn(2560, 320) * 0.05, torch.randn(2560))
+    w1, b1 = w1.to(DEV), b1.to(DEV)
+    w2, b2 = rnd(320, 1280, seed=21, scale=0.03), rnd(320, seed=22, dtype=torch.float32)
+    assert torch.equal(t.ff_geglu_fused(x0, w1, b1, w2, b2, ln_eps=1e-5), c.ff_geglu_fused(x0, w1, b1, w2, b2, ln_eps=1e-5))
+    wqkv, bqkv = rnd(960, 320, seed=23, scale=0.05), rnd(960, seed=24, dtype=torch.float32)
+    wo, bo = rnd(320, 320, seed=25, scale=0.05), rnd(320, seed=26, dtype=torch.float32)
+    kwt = dict(b=2, t=16, hw=40, heads=5, ln_eps=1e-5)
+    assert torch.equal(t.temporal_attn_fused(x0, wqkv, bqkv, wo, bo, **kwt), c.temporal_attn_fused(x0, wqkv, bqkv, wo, bo, **kwt))
 
 
 def test_tiny_unet_through_torch_op_layer(both, tiny_sd):

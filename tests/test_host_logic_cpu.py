@@ -421,7 +421,7 @@ def test_encoder_tiny_host_logic(tiny_sd, emu_fp32):
 
 
 def test_conv_halo_model_design_artifact():
-    """scripts/conv_halo_model.py (the data movement planned for the tap-reuse 3x3 convolution):
+    """scripts/conv_halo_model.py (the data movement planned for the tap-reuse 3x3 convolution, docs/LAB_NOTEBOOK.md section 8):
     exact against a direct convolution on a ragged image, and bank-conflict-free for every tap."""
     import importlib.util
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "conv_halo_model.py")

@@ -15,7 +15,8 @@ def t():
 
 def test_operator_namespace_and_abi(t):
     assert int(t.abi_version()) == _lib.TC_ABI_VERSION
-    for name in ("gemm", "quant_mxfp8", "gemm_mx", "attention", "attention_temporal", "groupnorm", "layernorm", "ddim_step"):
+    for name in ("gemm", "quant_mxfp8", "gemm_mx", "attention", "attention_temporal", "groupnorm", "layernorm", "ddim_step",
+                 "ff_geglu_fused", "temporal_attn_fused"):
         op = getattr(t, name)
         schema = str(op.default._schema)
         assert schema.startswith(f"tooncrafter::{name}("), schema
@@ -45,6 +46,13 @@ def test_meta_kernels_infer_shapes(t):
     x = torch.empty(5120, 1280, **bf)
     g = torch.empty(1280, **f32)
     assert t.groupnorm(x, g, g, 32, 160, 1e-5, True).shape == x.shape and t.layernorm(x, g, g, 1e-5).dtype == torch.bfloat16
+    # the level-0 one-launch operators (ABI 9): rows in, rows out
+    x0r = torch.empty(81920, 320, **bf)
+    y = t.ff_geglu_fused(x0r, torch.empty(2560, 320, **bf), torch.empty(2560, **f32), torch.empty(320, 1280, **bf), torch.empty(320, **f32), 1e-5)
+    assert y.shape == (81920, 320) and y.dtype == torch.bfloat16
+    y = t.temporal_attn_fused(x0r, torch.empty(960, 320, **bf), torch.empty(960, **f32), torch.empty(320, 320, **bf), torch.empty(320, **f32),
+                              2, 16, 2560, 5, 1e-5, 0.125)
+    assert y.shape == (81920, 320)
     lat = torch.empty(1, 4, 16, 40, 64, **f32)
     xp, x0 = t.ddim_step(lat, lat, lat, lat, None, 7.5, 7.5, 0.7, 0.6, 0.8, 0.7, 0.5, 0.3, 0.98)
     assert xp.shape == lat.shape and x0.shape == lat.shape

@@ -9,7 +9,7 @@
 //   a clip with the 3x3 convolutions here: 8.29 / 8.30 vs 8.20 / 8.21 frames/s (+1.1 %)
 // so the ROUTING is: 3x3 convolutions of UNet levels 0-2 by default; the temporal geometry only on request
 // (TC_CONV_HALO_T3=1) and in the strict test mode.  Round 4 PREDICTED 1.3x from an additive model of the request traffic
-// (DESIGN.md 5.5 (11)); the A bytes fell 6.7x as designed and the time fell 5 %: the 160-tile K loop was not waiting for
+// (docs/LAB_NOTEBOOK.md 5.5 (11)); the A bytes fell 6.7x as designed and the time fell 5 %: the 160-tile K loop was not waiting for
 // those bytes.  The GroupNorm prologue this kernel carried (ABI 10, tc_conv_gn_bf16: normalise the halo in registers)
 // was parity-green and LOST 4 % of a clip (7.80 / 7.81 vs 8.15 / 8.18 frames/s: +8 % convolution time for -0.7 ms of
 // GroupNorm, whose statistics pass + finalize stay): removed in ABI 11.
@@ -18,7 +18,7 @@
 // input pixel goes L2 -> LDS nine times per output-column tile (three times for the temporal taps).  The timing builds
 // of round 4 (profiles/r04_g16_ablate.txt) say what that costs on the level-0 3x3 convolution: 145 us with all
 // requests, 104 without A's, 91 without any -- and the chip's L2->LDS path delivers 12.6-18 TB/s inside a GEMM against
-// the 31 TB/s a 160x160x64 step needs at the MFMA roof.  Here a block owns a 2-D PATCH of the output:
+// the 31 TB/s a 160x160x64 step needs at the MFMA roof (docs/LAB_NOTEBOOK.md 5.5).  Here a block owns a 2-D PATCH of the output:
 //   3x3     : 10 image rows x 16 pixels of one frame        -> halo 12 x 18 = 216 pixels
 //   temporal: 10 consecutive pixels x the clip's 16 frames  -> halo 10 x 18 = 180 (frames -1 and 16 are the zero padding)
 // = 160 GEMM rows either way, tile row = 16 y + x, so one 16-row MFMA block is one image row (one pixel's frames).  Per
@@ -64,7 +64,7 @@ using ChGeo = chx::Shape<GATHER, WM>;                      // TAPS, PY, HY, NPIX
 
 // KS = 2 (TC_CONV_HALO_KSPLIT, WM = 2 only): the K loop split over TWO 4-wave groups inside one 8-wave block -- for the
 // launches whose patches do not fill the chip (level 2: 256 tiles on 256 CUs = one 4-wave block per CU, one MFMA wave per
-// SIMD, which reaches 45 % of the matrix pipe where two reach 70 %: DESIGN.md 5.5).  Group g owns the channel chunks
+// SIMD, which reaches 45 % of the matrix pipe where two reach 70 %: docs/LAB_NOTEBOOK.md 5.5).  Group g owns the channel chunks
 // [g nch / 2, (g + 1) nch / 2) with its OWN halo buffer and W stages (2 x 68 KiB of LDS), both groups run the same loop in
 // lockstep (the barriers are the block's), and at the end group 1 hands its accumulators to group 0 through LDS (fixed
 // order: acc0 + acc1), which runs the epilogue.  Unlike the split over blocks (TC_GEMM_SPLITK) no fp32 partial tile

@@ -2,7 +2,8 @@
 //
 // The reference binds ATen / xformers operators from Python (utils/utils.py:27-42 instantiates lvdm classes whose
 // forward methods call torch ops); this registers the MI355X kernels as first-class torch operators instead:
-//   torch.ops.tooncrafter.gemm / quant_mxfp8 / gemm_mx / attention / attention_temporal / groupnorm / layernorm / ddim_step
+//   torch.ops.tooncrafter.gemm / quant_mxfp8 / gemm_mx / attention / attention_temporal / groupnorm / layernorm / ddim_step /
+//   ff_geglu_fused / temporal_attn_fused
 // with (i) a CUDA(HIP)-key implementation that validates the tensors, allocates the result from the caching allocator,
 // picks up the CURRENT stream and calls the same extern "C" entry point the ctypes binding calls, and (ii) a Meta-key
 // implementation (shape / dtype inference only) so the ops can be traced, exported and shape-checked without a GPU.
@@ -226,6 +227,60 @@ Tensor groupnorm_cuda(const Tensor& x, const Tensor& gamma, const Tensor& beta, 
   return y;
 }
 
+// ---- the level-0 one-launch operators (ABI 9): LayerNorm + GEGLU feed-forward + residual; LayerNorm + temporal self-attention +
+// residual (lvdm/modules/attention.py:81-144,225-246,415-442).  ln_eps < 0: x is taken as already normalised.
+void check_w(const Tensor& t, at::ScalarType dt, const char* name) {
+  TORCH_CHECK(t.is_cuda() && t.scalar_type() == dt && t.is_contiguous(), name, ": expected a contiguous CUDA tensor of dtype ", dt);
+}
+
+Tensor ff_geglu_fused_cuda(const Tensor& x, const Tensor& w1, const Tensor& b1, const Tensor& w2, const Tensor& b2, double ln_eps) {
+  check_rows(x, "ff_geglu_fused: x");
+  check_w(w1, at::kBFloat16, "ff_geglu_fused: w1"); check_w(w2, at::kBFloat16, "ff_geglu_fused: w2");
+  check_w(b1, at::kFloat, "ff_geglu_fused: b1"); check_w(b2, at::kFloat, "ff_geglu_fused: b2");
+  const int64_t m = x.size(0), c = x.size(1);
+  TORCH_CHECK(w2.dim() == 2 && w1.dim() == 2, "ff_geglu_fused: w1 [2 hidden, c], w2 [c, hidden]");
+  const int64_t hidden = w2.size(1);
+  TORCH_CHECK(w1.size(0) == 2 * hidden && w1.size(1) == c && w2.size(0) == c && b1.numel() == 2 * hidden && b2.numel() == c,
+              "ff_geglu_fused: x [m, c] rows, w1 [2 hidden, c], b1 [2 hidden], w2 [c, hidden], b2 [c]");
+  Tensor out = at::empty({m, c}, x.options());
+  TcFfParams p{};
+  p.x = bf(x); p.w1 = bf(w1); p.b1 = b1.data_ptr<float>(); p.w2 = bf(w2); p.b2 = b2.data_ptr<float>();
+  p.out = reinterpret_cast<tc_bf16*>(out.data_ptr());
+  p.m = (int32_t)m; p.c = (int32_t)c; p.hidden = (int32_t)hidden; p.ldx = (int32_t)x.stride(0); p.ldo = (int32_t)c;
+  p.ln = ln_eps >= 0.0 ? 1 : 0; p.ln_eps = ln_eps >= 0.0 ? (float)ln_eps : 0.f;
+  check_rc(tc_ff_geglu_fused(&p, cur_stream()), "tc_ff_geglu_fused");
+  return out;
+}
+
+Tensor ff_geglu_fused_meta(const Tensor& x, const Tensor&, const Tensor&, const Tensor&, const Tensor&, double) {
+  return at::empty({x.size(0), x.size(1)}, x.options());
+}
+
+Tensor temporal_attn_fused_cuda(const Tensor& x, const Tensor& wqkv, const Tensor& bqkv, const Tensor& wo, const Tensor& bo, int64_t b,
+                                int64_t t, int64_t hw, int64_t heads, double ln_eps, double scale) {
+  check_rows(x, "temporal_attn_fused: x");
+  check_w(wqkv, at::kBFloat16, "temporal_attn_fused: wqkv"); check_w(wo, at::kBFloat16, "temporal_attn_fused: wo");
+  check_w(bqkv, at::kFloat, "temporal_attn_fused: bqkv"); check_w(bo, at::kFloat, "temporal_attn_fused: bo");
+  const int64_t m = x.size(0), c = x.size(1);
+  TORCH_CHECK(m == b * t * hw && wqkv.dim() == 2 && wqkv.size(0) == 3 * c && wqkv.size(1) == c && wo.dim() == 2 && wo.size(0) == c &&
+              wo.size(1) == c && bqkv.numel() == 3 * c && bo.numel() == c && c == heads * 64,
+              "temporal_attn_fused: x [b*t*hw, c] rows, wqkv [3c, c], bqkv [3c], wo [c, c], bo [c], c = heads * 64");
+  Tensor out = at::empty({m, c}, x.options());
+  TcTbParams p{};
+  p.x = bf(x); p.wqkv = bf(wqkv); p.bqkv = bqkv.data_ptr<float>(); p.wo = bf(wo); p.bo = bo.data_ptr<float>();
+  p.out = reinterpret_cast<tc_bf16*>(out.data_ptr());
+  p.b = (int32_t)b; p.t = (int32_t)t; p.hw = (int32_t)hw; p.c = (int32_t)c; p.heads = (int32_t)heads;
+  p.ldx = (int32_t)x.stride(0); p.ldo = (int32_t)c;
+  p.ln = ln_eps >= 0.0 ? 1 : 0; p.ln_eps = ln_eps >= 0.0 ? (float)ln_eps : 0.f; p.scale = (float)scale;
+  check_rc(tc_temporal_attn_fused(&p, cur_stream()), "tc_temporal_attn_fused");
+  return out;
+}
+
+Tensor temporal_attn_fused_meta(const Tensor& x, const Tensor&, const Tensor&, const Tensor&, const Tensor&, int64_t, int64_t, int64_t,
+                                int64_t, double, double) {
+  return at::empty({x.size(0), x.size(1)}, x.options());
+}
+
 Tensor layernorm_cuda(const Tensor& x, const Tensor& gamma, const Tensor& beta, double eps) {
   check_rows(x, "layernorm: x");
   TORCH_CHECK(x.is_contiguous(), "layernorm: x must be contiguous");
@@ -280,6 +335,8 @@ TORCH_LIBRARY(tooncrafter, m) {
         "Tensor? k2, Tensor? v2, int lk2, int kv2_bdiv) -> Tensor");
   m.def("attention_temporal(Tensor qkv, int b, int t, int hw, int heads, float scale) -> Tensor");
   m.def("groupnorm(Tensor x, Tensor gamma, Tensor beta, int samples, int rows, float eps, bool silu) -> Tensor");
+  m.def("ff_geglu_fused(Tensor x, Tensor w1, Tensor b1, Tensor w2, Tensor b2, float ln_eps) -> Tensor");
+  m.def("temporal_attn_fused(Tensor x, Tensor wqkv, Tensor bqkv, Tensor wo, Tensor bo, int b, int t, int hw, int heads, float ln_eps, float scale) -> Tensor");
   m.def("layernorm(Tensor x, Tensor gamma, Tensor beta, float eps) -> Tensor");
   m.def("ddim_step(Tensor x, Tensor e_cond, Tensor? e_uncond, Tensor? noise, Tensor? e_uncond_img, float cfg_scale, "
         "float cfg_img, float guidance_rescale, float sqrt_ac, float sqrt_1m_ac, float sqrt_a_prev, float dir_coef, "
@@ -296,6 +353,8 @@ TORCH_LIBRARY_IMPL(tooncrafter, CUDA, m) {
   m.impl("groupnorm", groupnorm_cuda);
   m.impl("layernorm", layernorm_cuda);
   m.impl("ddim_step", ddim_step_cuda);
+  m.impl("ff_geglu_fused", ff_geglu_fused_cuda);
+  m.impl("temporal_attn_fused", temporal_attn_fused_cuda);
 }
 
 TORCH_LIBRARY_IMPL(tooncrafter, Meta, m) {
@@ -307,6 +366,8 @@ TORCH_LIBRARY_IMPL(tooncrafter, Meta, m) {
   m.impl("groupnorm", like_meta3);
   m.impl("layernorm", like_meta_ln);
   m.impl("ddim_step", ddim_step_meta);
+  m.impl("ff_geglu_fused", ff_geglu_fused_meta);
+  m.impl("temporal_attn_fused", temporal_attn_fused_meta);
 }
 
 TORCH_LIBRARY_IMPL(tooncrafter, CompositeExplicitAutograd, m) {

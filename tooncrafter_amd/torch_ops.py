@@ -80,6 +80,13 @@ class TorchLibOps(HipOps):
     def attention_temporal(self, qkv, *, b, t, hw, heads, scale=None):
         return self.t.attention_temporal(qkv, b, t, hw, heads, float(64 ** -0.5 if scale is None else scale))
 
+    def ff_geglu_fused(self, x, w1, b1, w2, b2, *, ln_eps=None):
+        return self.t.ff_geglu_fused(x, w1, b1, w2, b2, -1.0 if ln_eps is None else float(ln_eps))
+
+    def temporal_attn_fused(self, x, wqkv, bqkv, wo, bo, *, b, t, hw, heads, ln_eps=None, scale=None):
+        return self.t.temporal_attn_fused(x, wqkv, bqkv, wo, bo, int(b), int(t), int(hw), int(heads),
+                                          -1.0 if ln_eps is None else float(ln_eps), float(64 ** -0.5 if scale is None else scale))
+
     def groupnorm(self, x, gamma, beta, *, samples, rows, eps, silu=False, part=None):
         if part is not None:
             return super().groupnorm(x, gamma, beta, samples=samples, rows=rows, eps=eps, silu=silu, part=part)
