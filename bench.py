@@ -443,13 +443,14 @@ def rocm_eager_baseline(model, inp):
             "sample": "4 B=1 UNet forwards (2 guided DDIM steps) + one 16-frame decode; one clip = 100 forwards + 30/16 decodes"}
 
 
-def torch_binding_clip(args):
-    """The binding BASELINE.json's north_star names -- PyTorch-ROCm custom ops (TORCH_LIBRARY(tooncrafter), csrc/torch_ops.cpp,
-    TC_BINDING=torch) -- timed on the same workload in a CHILD process (the binding is chosen when the operator backend is
-    created): 2 timed clips after 1 warm-up, default flags otherwise.  The headline runs on the ctypes binding (DESIGN.md 1:
-    measured equivalent; both call the same C ABI)."""
+def other_binding_clip(args):
+    """The headline runs on the binding BASELINE.json's north_star names -- PyTorch-ROCm custom ops (TORCH_LIBRARY(tooncrafter),
+    csrc/torch_ops.cpp; the default since round 5).  This times the OTHER binding over the same C ABI (ctypes; or the custom ops
+    if the headline ran under TC_BINDING=ctypes) on the same workload in a CHILD process (the binding is chosen when the operator
+    backend is created): 2 timed clips after 1 warm-up, default flags otherwise."""
     import subprocess
-    env = dict(os.environ, TC_BINDING="torch")
+    other = "ctypes" if getattr(ops.backend(), "binding", "ctypes") == "torch" else "torch"
+    env = dict(os.environ, TC_BINDING=other)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--ddim-steps", str(args.ddim_steps),
@@ -460,7 +461,7 @@ def torch_binding_clip(args):
         if r.returncode != 0 or not line:
             return {"error": f"rc {r.returncode}", "stderr_tail": r.stderr[-400:]}
         d = json.loads(line[-1])
-        return {"binding": "TORCH_LIBRARY(tooncrafter) via TC_BINDING=torch", "value": d["value"], "unit": d["unit"], "steps": d["steps"],
+        return {"binding": d.get("binding", other), "value": d["value"], "unit": d["unit"], "steps": d["steps"],
                 "ms_per_step": d["ms_per_step"], "lease_calibration": d.get("lease_calibration", {}).get("after_timed_region")}
     except Exception as e:                                       # noqa: BLE001  (an extra must never cost the headline)
         return {"error": f"{type(e).__name__}: {e}"}
@@ -675,7 +676,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the after-the-fact extras (ROCm-eager baseline, one clip through the TORCH_LIBRARY binding)")
+                    help="skip the after-the-fact extras (ROCm-eager baseline, two clips through the other binding)")
     ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--retry", action="store_true",
                     help="supervise the run in a child process and repeat it ONLY if the lease itself is unhealthy "
@@ -784,6 +785,8 @@ def main():
             "mfma_fraction_whole_clip": round(TFLOP_CLIP * args.steps * clips_per_step / dt / PEAK_BF16_TFLOPS, 4)
             if args.ddim_steps == 50 else None,
             "output_finite": finite,
+            "binding": ("torch.ops.tooncrafter (TORCH_LIBRARY custom ops over the C ABI)" if getattr(ops.backend(), "binding", "ctypes") == "torch"
+                        else "ctypes over the C ABI"),
             **evidence,
         }
         mm = 0.5 * (calib_pre["matmul_8192_bf16_tflops"] + calib_post["matmul_8192_bf16_tflops"])
@@ -830,8 +833,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras and bdec == 0:
         result["rocm_eager_baseline"] = rocm_eager_baseline(model, inps[0])
         _log("rocm eager baseline done")
-        result["torch_binding"] = torch_binding_clip(args)
-        _log("torch binding clip done")
+        result["binding_ab"] = other_binding_clip(args)
+        _log("other binding clip done")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(model, inps[0])
     if rank == 0:

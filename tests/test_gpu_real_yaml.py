@@ -1,7 +1,7 @@
 """Drop-in boundary on the real thing: the reference's own configs/inference_512_v1.0.yaml values
 (tests/golden/inference_512_v1.0.model.yaml) instantiated through `instantiate_from_config` on the HIP backend -- with the
-PyTorch-ROCm custom-op binding north_star names (TC_BINDING=torch, TORCH_LIBRARY(tooncrafter)) and with the default
-ctypes binding --, a strict load of a synthetic checkpoint in the reference's format, and `image_guided_synthesis` for
+PyTorch-ROCm custom-op binding north_star names (TORCH_LIBRARY(tooncrafter), the default) and with the ctypes
+binding (TC_BINDING=ctypes) --, a strict load of a synthetic checkpoint in the reference's format, and `image_guided_synthesis` for
 2 DDIM steps at 320 x 512 x 16 frames (reference scripts/evaluation/inference.py:180-277, 280-344).
 The work is done by tests/real_yaml_run.py in a subprocess (the binding is chosen when the backend is created)."""
 import json

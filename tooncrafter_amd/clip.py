@@ -102,11 +102,13 @@ class SamplingPlan:
 def sample(model, cond: Conditions, plan: SamplingPlan, latent_shape, x_T=None):
     """Latents (b, 4, t, h, w) of one clip batch."""
     sampler = (ThreeWaySampler if cond.three_way else DDIMSampler)(model)
+    extra = dict(plan.extra)
+    x_T = extra.pop("x_T", x_T)                    # the reference's callers hand the start noise over among their **kwargs
     out, _ = sampler.sample(S=plan.steps, conditioning=cond.positive, batch_size=latent_shape[0], shape=tuple(latent_shape[1:]),
                             verbose=False, unconditional_guidance_scale=plan.scale, unconditional_conditioning=cond.negative,
                             eta=plan.eta, cfg_img=plan.image_scale, mask=None, x0=None, fs=cond.fs,
                             timestep_spacing=plan.spacing, guidance_rescale=plan.rescale, x_T=x_T,
-                            unconditional_conditioning_img_nonetext=cond.image_only, **plan.extra)
+                            unconditional_conditioning_img_nonetext=cond.image_only, **extra)
     return out
 
 

@@ -628,14 +628,35 @@ _backend = None
 
 
 def backend():
+    """The operator set behind `ops.gemm(...)` etc.  Two bindings over the ONE C ABI (include/tooncrafter_hip.h):
+      TC_BINDING=torch (default since round 5): PyTorch-ROCm custom ops, `torch.ops.tooncrafter.*` (csrc/torch_ops.cpp,
+        TORCH_LIBRARY with CUDA + Meta keys) -- the binding BASELINE.json's north_star names;
+      TC_BINDING=ctypes: the same entry points through ctypes.
+    Bit-identical (tests/test_gpu_torch_ops.py) and equally fast (bench.py `binding_ab`; both replay hipGraphs).  Either way
+    libtooncrafter_hip.so is mandatory: no kernel library, no backend (HipOps raises).  If only the custom-op layer
+    (libtooncrafter_torch.so, host C++) is missing, the ctypes binding takes over with one line on stderr -- unless TC_BINDING=torch
+    was asked for explicitly, which then fails."""
     global _backend
     if _backend is None:
         import os
-        if os.environ.get("TC_BINDING", "ctypes") == "torch":      # the TORCH_LIBRARY op layer over the same C ABI
-            from .torch_ops import TorchLibOps
-            _backend = TorchLibOps()
-        else:
+        import sys
+        want = os.environ.get("TC_BINDING", "").lower()
+        if want in ("", "torch"):
+            _lib.load()                                              # the kernel library first: its absence is fatal either way
+            from . import torch_ops
+            try:
+                torch_ops.load()
+            except Exception as e:                                   # noqa: BLE001  (missing / unloadable op library)
+                if want == "torch":
+                    raise
+                sys.stderr.write(f"[tooncrafter_amd] custom-op layer unavailable ({type(e).__name__}: {e}); using the ctypes binding\n")
+                _backend = HipOps()
+            else:
+                _backend = torch_ops.TorchLibOps()
+        elif want == "ctypes":
             _backend = HipOps()   # raises if libtooncrafter_hip.so is missing: no fallback
+        else:
+            raise ValueError(f"TC_BINDING={want!r}: expected 'torch' or 'ctypes'")
     return _backend
 
 
