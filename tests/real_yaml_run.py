@@ -9,7 +9,7 @@ the backend exists): the reference's REAL configuration on the HIP backend, end 
      (OpenCLIP ViT-H/14 towers and the Resampler included);
   3. a synthetic checkpoint in the reference's format ({"state_dict": ...}) is loaded with `strict=True`
      (inference.py:28-32);
-  4. `image_guided_synthesis` (inference.py:180-277, mirrored in tooncrafter_amd/pipeline.py) runs 2 DDIM steps at
+  4. `image_guided_synthesis` (inference.py:180-277, as tooncrafter_amd/clip.py exposes it) runs 2 DDIM steps at
      320 x 512 x 16 frames with CFG 7.5 from a start / end frame pair, exactly as inference.py:324-342 calls it.
 Prints one JSON line.
 """
@@ -65,7 +65,7 @@ def main():
     model.eval()
     t_load = time.time() - t0 - t_build
 
-    from tooncrafter_amd.pipeline import image_guided_synthesis
+    from tooncrafter_amd.clip import image_guided_synthesis
     g = torch.Generator().manual_seed(5)
     fa, fb = (torch.rand(1, 3, 1, 320, 512, generator=g) * 2 - 1 for _ in range(2))
     videos = torch.cat([fa.repeat(1, 1, 8, 1, 1), fb.repeat(1, 1, 8, 1, 1)], dim=2).cuda(0)      # load_data_prompts, interp

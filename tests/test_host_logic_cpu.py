@@ -322,7 +322,7 @@ def test_openclip_conditioners_resolve_and_carry_open_clip_names():
 
 
 def test_pipeline_matches_reference_image_guided_synthesis(tiny_sd):
-    """The caller row: tooncrafter_amd.pipeline.image_guided_synthesis against the reference's own function
+    """The caller row: tooncrafter_amd.clip.image_guided_synthesis (the adapter onto Conditions.build -> sample -> decode_spliced) against the reference's own function
     (scripts/evaluation/inference.py:180-277) run on the tiny model with the shared deterministic conditioner
     stand-ins -- conditioning assembly, first/last-frame encode (2 frames instead of T), c_concat, uncond branch,
     sampler call, both decodes and the centre-frame splice."""
