@@ -1,0 +1,291 @@
+// 256x256-tile bf16 MFMA GEMM on FOUR waves -- one per SIMD, 128x128 outputs each, all 256 accumulators of a lane in AGPRs --
+// for the linear problems whose tiles fill the chip: nn.Linear of lvdm/modules/attention.py:415-442 (the GEGLU projections and ff2
+// of UNet levels 1 / 2), square problems.  gfx950.
+//
+// Why this shape.  Round 5 disassembled what hipBLASLt runs where it beats this library by 25-40 % (8192^3: 1.62 vs 1.23 PF/s;
+// DESIGN.md 5.6 (4)): a 256x256x64 tile on four waves, each owning 8 x 8 v_mfma_f32_16x16x32_bf16 tiles.  Per K-step a wave
+// issues 128 MFMAs from 32 ds_read_b128 (0.25 reads per MFMA: the 8-wave kernel of gemm8.hip needs 0.75, the 160-tile of
+// gemm16.hip 0.4 -- and LDS bandwidth is the measured ceiling of both) and 16 LDS-DMA requests, and every one of those sits
+// in the shadow of a 16-cycle MFMA, so ONE wave per SIMD keeps the matrix pipe busy: no second wave to share registers with,
+// hence the 128x128 wave tile.  This kernel is that structure in HIP C++: gemm16.hip's two-fragment-set software pipeline
+// (fragments of the next K-slice requested before the current slice's MFMAs; tile requests from inline asm between the MFMA
+// rows; one counted wait + one raw barrier per K-step), scaled to 8 x 8 tiles per wave.
+//
+//   per K-step kb (stage st = kb & 1):
+//     fragments of slice 1 of step kb  ->  set 1          | 64 MFMAs of slice 0 (set 0)
+//     s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier            : every wave has read stage st; step kb + 1 has landed in stage st ^ 1
+//     fragments of slice 0 of step kb + 1  ->  set 0      | 64 MFMAs of slice 1 (set 1), the 16 requests of step kb + 2
+//                                                           (into stage st) in pairs between the MFMA rows
+//   A request is waited for one whole K-step (2048 matrix cycles) after it was issued.
+// LDS: 2 stages x (256 + 256) rows x 128 B = 128 KiB (one block per CU), XOR swizzle (row >> 1) & 7 on the SOURCE chunk of the
+// DMA as everywhere (conflict-free ds_read_b128 of the 16x16x32 operand layout from 16-aligned row blocks).
+// Epilogue: per wave eight passes of one 16-row tile row through a private fp32 slab [16][128 + 4] in the idle stage buffers,
+// then 16-byte row vectors (bias / row bias / activation / residual, or the GEGLU product of the per-32 packed columns).
+// Linear gather only; the convolutions that dominate the UNet have N = 320 / 640 and would need a 256x160 variant with a
+// gather -- not built.
+#include "gemm_persist.h"
+
+#include <stdlib.h>
+
+namespace {
+
+constexpr int G4_BM = 256, G4_BN = 256, G4_THREADS = 256;
+constexpr int G4_WT = 128;                                   // wave tile
+constexpr int G4_NT = G4_WT / 16;                            // 8 MFMA tiles per wave-tile side
+constexpr int G4_STAGE = (G4_BM + G4_BN) * TC_BK * 2;        // 64 KiB
+constexpr int G4_RSTEP = G4_THREADS / 8;                     // rows per loader pass: 32
+constexpr int G4_R = G4_BM / G4_RSTEP;                       // loader passes over the A rows (and over the W rows): 8
+constexpr int G4_PIECE = G4_RSTEP * TC_BK * 2;               // LDS bytes from one loader pass to the next: 4 KiB
+constexpr int G4_SLAB_LD = G4_WT + 4;                        // fp32 slab row stride: +4 keeps the four row groups of a spill on distinct banks
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// The MFMA from inline asm with its accumulator pinned to AGPRs ("+a").  With the builtin, hipcc's register allocator split the
+// 256 accumulators between AGPRs and VGPRs in the loop that also carries the request asm and moved them back and forth around
+// every MFMA (392 v_accvgpr_* per 64 MFMAs in the ISA); pinned, a K-step is 128 MFMAs + 32 ds_read_b128 + 16 requests and
+// nothing else.  Operand hazards the compiler cannot see through the asm: the operands come from ds_read_b128 (its waitcnt
+// pass does guard asm register operands), the results are first read by VALU in the epilogue, behind a barrier.
+__device__ __forceinline__ void g4_mfma(f32x4_t& c, const bf16x8& a, const bf16x8& b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
+template <bool GEGLU>
+__global__ __launch_bounds__(G4_THREADS) void gemm4_kernel(const TcGemmParams p, const int total_tiles) {
+  __shared__ __attribute__((aligned(1024))) char smem[2 * G4_STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+  const int tiles_n = (p.n + G4_BN - 1) / G4_BN;
+  const int tiles_m = (p.m + G4_BM - 1) / G4_BM;
+  int tile_m, tile_n;
+  g8_tile_of(blockIdx.x, tiles_m, tiles_n, total_tiles, tile_m, tile_n);
+
+  const int64_t bz = blockIdx.z;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;     // LDS byte address of smem
+  const g8_srd_t w_srd = g8_make_srd(reinterpret_cast<const bf16_t*>(p.w) + bz * p.stride_w, tc_w_extent(p));
+  const g8_srd_t a_srd = g8_make_srd(reinterpret_cast<const bf16_t*>(p.a) + bz * p.stride_a + (int64_t)tile_m * G4_BM * p.lda,
+                                     tc_a_extent(p) - (int64_t)tile_m * G4_BM * p.lda * 2);
+
+  // ---- loader geometry (gemm16.hip): thread -> (row lrow + 32 q, 16-byte chunk), swizzle on the SOURCE chunk; one wave
+  // instruction fills 1 KiB = 8 rows
+  const int lrow = tid >> 3;
+  const int chunk = (tid & 7) ^ ((lrow >> 1) & 7);
+  uint32_t a_voff[G4_R], b_voff[G4_R];
+#pragma unroll
+  for (int q = 0; q < G4_R; ++q) {
+    const int ml = lrow + G4_RSTEP * q;
+    a_voff[q] = tile_m * G4_BM + ml < p.m ? (uint32_t)((int64_t)ml * p.lda * 2 + chunk * 16) : TC_OOB;
+    const int n = tile_n * G4_BN + ml;
+    b_voff[q] = n < p.n ? (uint32_t)((int64_t)n * p.ldw * 2 + chunk * 16) : TC_OOB;
+  }
+  const int nk = (p.k + TC_BK - 1) / TC_BK;
+  const bool k_ragged = (p.k & (TC_BK - 1)) != 0;
+
+  uint32_t r_soff = 0, r_dst = 0;
+  auto prep = [&](int kb, int stage) {
+    const int k0 = kb * TC_BK;
+    if (k_ragged && kb == nk - 1) {                       // the K tail: its chunks are zero-filled by an out-of-range offset; only
+      const uint32_t kill = (k0 + chunk * 8 >= p.k) ? TC_OOB : 0u;      // the tile's LAST requests see it (chunk = the SOURCE chunk)
+#pragma unroll
+      for (int q = 0; q < G4_R; ++q) { a_voff[q] |= kill; b_voff[q] |= kill; }
+    }
+    r_soff = (uint32_t)k0 * 2u;
+    r_dst = lds0 + (uint32_t)(stage * G4_STAGE + wave_u * 1024);
+  };
+  // piece q of the prepared K-step: 0..7 = W row passes, 8..15 = A row passes
+  auto issue_piece = [&](auto Q_) {
+    constexpr int q = decltype(Q_)::value;
+    if constexpr (q < G4_R) g8_dma16(w_srd, r_dst + G4_BM * TC_BK * 2 + q * G4_PIECE, b_voff[q], r_soff);
+    else g8_dma16(a_srd, r_dst + (q - G4_R) * G4_PIECE, a_voff[q - G4_R], r_soff);
+  };
+  auto issue_all = [&]() {
+    issue_piece(ic<0>{}); issue_piece(ic<1>{}); issue_piece(ic<2>{}); issue_piece(ic<3>{});
+    issue_piece(ic<4>{}); issue_piece(ic<5>{}); issue_piece(ic<6>{}); issue_piece(ic<7>{});
+    issue_piece(ic<8>{}); issue_piece(ic<9>{}); issue_piece(ic<10>{}); issue_piece(ic<11>{});
+    issue_piece(ic<12>{}); issue_piece(ic<13>{}); issue_piece(ic<14>{}); issue_piece(ic<15>{});
+  };
+
+  f32x4_t acc[G4_NT][G4_NT];
+#pragma unroll
+  for (int i = 0; i < G4_NT; ++i)
+#pragma unroll
+    for (int j = 0; j < G4_NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // v_mfma_f32_16x16x32_bf16 operands: lane holds row (lane & 15) of its 16-row tile, k = 8 (lane >> 4) .. +7 of the 32-deep
+  // slice -> one ds_read_b128 at 16-byte chunk 4 ks + (lane >> 4) of that row; tile rows step by 16, so (row >> 1) & 7 is the lane's
+  const int frow = lane & 15;
+  const int fq = lane >> 4;
+  const int a_row0 = (wm * G4_WT + frow) * (TC_BK * 2);
+  const int b_row0 = G4_BM * TC_BK * 2 + (wn * G4_WT + frow) * (TC_BK * 2);
+  const int f_sw = (frow >> 1) & 7;                          // wm * 128 and wn * 128 are multiples of 16: they do not enter
+  auto read_frags = [&](int stage, int ks, bf16x8 (&af)[G4_NT], bf16x8 (&bf)[G4_NT]) {
+    const char* s0 = smem + stage * G4_STAGE + (((ks * 4 + fq) ^ f_sw) << 4);
+#pragma unroll
+    for (int i = 0; i < G4_NT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(s0 + a_row0 + i * (16 * TC_BK * 2));
+#pragma unroll
+    for (int j = 0; j < G4_NT; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(s0 + b_row0 + j * (16 * TC_BK * 2));
+  };
+  auto mma_row = [&](auto I_, const bf16x8 (&af)[G4_NT], const bf16x8 (&bf)[G4_NT]) {
+    constexpr int i = decltype(I_)::value;
+#pragma unroll
+    for (int j = 0; j < G4_NT; ++j) g4_mfma(acc[i][j], af[i], bf[j]);
+  };
+
+  // ---- main loop
+  prep(0, 0);
+  issue_all();
+  if (nk > 1) {
+    prep(1, 1);
+    issue_all();
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");        // step 0 has landed, the 16 requests of step 1 may be in flight
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  g8_barrier();
+  bf16x8 af0[G4_NT], bf0[G4_NT], af1[G4_NT], bf1[G4_NT];
+  read_frags(0, 0, af0, bf0);
+  // one K-step; ISSUE: the 16 requests of step kb + 2 go out between the MFMA rows of the second slice.  Two loops (all steps
+  // but the last two issue) instead of a run-time condition around every pair of requests: no branches inside a step
+  auto kstep = [&](auto ISSUE_, int kb) {
+    constexpr bool ISSUE = decltype(ISSUE_)::value != 0;
+    const int st = kb & 1;
+    read_frags(st, 1, af1, bf1);
+    mma_row(ic<0>{}, af0, bf0); mma_row(ic<1>{}, af0, bf0); mma_row(ic<2>{}, af0, bf0); mma_row(ic<3>{}, af0, bf0);
+    mma_row(ic<4>{}, af0, bf0); mma_row(ic<5>{}, af0, bf0); mma_row(ic<6>{}, af0, bf0); mma_row(ic<7>{}, af0, bf0);
+    __builtin_amdgcn_sched_barrier(0);                       // (hipcc otherwise sinks the MFMAs below the wait)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    g8_barrier();                                            // stage st is free, stage st ^ 1 is complete, for every wave
+    if constexpr (ISSUE) prep(kb + 2, st);
+    read_frags(st ^ 1, 0, af0, bf0);                         // (in the last step it reads a dead stage, nothing uses it)
+    // second slice: after every fourth MFMA one request (six scalar / vector-memory instructions: they issue in the shadow of the
+    // MFMA in flight; the MFMAs and the requests are both volatile asm, so this IS the instruction order)
+    auto row1 = [&](auto I_) {
+      constexpr int i = decltype(I_)::value;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g4_mfma(acc[i][j], af1[i], bf1[j]);
+      if constexpr (ISSUE) issue_piece(ic<2 * i>{});
+#pragma unroll
+      for (int j = 4; j < 8; ++j) g4_mfma(acc[i][j], af1[i], bf1[j]);
+      if constexpr (ISSUE) issue_piece(ic<2 * i + 1>{});
+    };
+    row1(ic<0>{}); row1(ic<1>{}); row1(ic<2>{}); row1(ic<3>{}); row1(ic<4>{}); row1(ic<5>{}); row1(ic<6>{}); row1(ic<7>{});
+  };
+  int kb = 0;
+  for (; kb + 2 < nk; ++kb) kstep(ic<1>{}, kb);
+  for (; kb < nk; ++kb) kstep(ic<0>{}, kb);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();                                           // the epilogue slabs reuse the stage buffers
+
+  // ---- epilogue: per wave, eight passes of one 16-row tile row through a private fp32 slab [16][132]
+  float* slab = reinterpret_cast<float*>(smem) + wave * (16 * G4_SLAB_LD);
+  const bf16_t* res_base = p.residual ? reinterpret_cast<const bf16_t*>(p.residual) + bz * p.stride_c : nullptr;
+  char* c_base = reinterpret_cast<char*>(p.c) + bz * p.stride_c * (p.out_f32 ? 4 : 2);
+  const int n_out = GEGLU ? p.n / 2 : p.n;
+  // this lane's 8 output columns are the same in every pass: vector column vc of the wave tile (GEGLU: of its 64 outputs)
+  constexpr int VPR = GEGLU ? G4_WT / 16 : G4_WT / 8;        // output vectors per slab row: 8 | 16
+  constexpr int QN = 16 * VPR / 64;                          // vectors per lane and pass: 2 | 4
+  const int vc = lane % VPR, lr0 = lane / VPR;
+  const int pc = GEGLU ? 32 * (vc >> 1) + (vc & 1) * 8 : vc * 8;          // slab column of the vector (GEGLU: of its VALUES; gates + 16)
+  const int n0 = (GEGLU ? (tile_n * G4_BN + wn * G4_WT) / 2 : tile_n * G4_BN + wn * G4_WT) + vc * 8;
+  const bool col_ok = n0 < n_out;
+  float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, bg[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (p.bias && col_ok) {
+    const float* bp = p.bias + (GEGLU ? tile_n * G4_BN + wn * G4_WT + pc : n0);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
+    if (GEGLU) {
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(bp + 16), g1 = *reinterpret_cast<const f32x4*>(bp + 20);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bg[e] = g0[e]; bg[4 + e] = g1[e]; }
+    }
+  }
+  auto epi_pass = [&](auto I_) {
+    constexpr int i = decltype(I_)::value;
+    // C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg
+#pragma unroll
+    for (int j = 0; j < G4_NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slab[(fq * 4 + r) * G4_SLAB_LD + j * 16 + frow] = acc[i][j][r];
+    // the same wave reads back (LDS operations of one wave complete in order)
+    const int row_base = tile_m * G4_BM + wm * G4_WT + i * 16;
+#pragma unroll
+    for (int q = 0; q < QN; ++q) {
+      const int lr = lr0 + q * (64 / VPR);
+      const int m = row_base + lr;
+      if (m < p.m && col_ok) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(slab + lr * G4_SLAB_LD + pc);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(slab + lr * G4_SLAB_LD + pc + 4);
+        float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        if (GEGLU) {
+          const f32x4 glo = *reinterpret_cast<const f32x4*>(slab + lr * G4_SLAB_LD + pc + 16);
+          const f32x4 ghi = *reinterpret_cast<const f32x4*>(slab + lr * G4_SLAB_LD + pc + 20);
+          const float gt[8] = {glo[0], glo[1], glo[2], glo[3], ghi[0], ghi[1], ghi[2], ghi[3]};
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) {                   // the arithmetic of gemm_epilogue.h (packed fp32 pairs)
+            const tc_f32x2 v = {x[e] * p.alpha + bv[e], x[e + 1] * p.alpha + bv[e + 1]};
+            const tc_f32x2 h = v * gelu_erf_f2(tc_f32x2{gt[e] * p.alpha + bg[e], gt[e + 1] * p.alpha + bg[e + 1]}) * p.out_scale;
+            x[e] = h[0]; x[e + 1] = h[1];
+          }
+        } else {
+          float rb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          if (p.row_bias) {
+            const float* rp = p.row_bias + (int64_t)(m / p.row_div) * p.ldrb + n0;
+            const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { rb[e] = r0[e]; rb[4 + e] = r1[e]; }
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = apply_act(x[e] * p.alpha + bv[e] + rb[e], p.act) * p.out_scale;
+          if (res_base) {
+            float rf[8];
+            unpack8(*reinterpret_cast<const u32x4*>(res_base + (int64_t)m * p.ldr + n0), rf);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] += rf[e];
+          }
+        }
+        if (p.out_f32) {
+          float* op = reinterpret_cast<float*>(c_base) + (int64_t)m * p.ldc + n0;
+          *reinterpret_cast<f32x4*>(op) = f32x4{x[0], x[1], x[2], x[3]};
+          *reinterpret_cast<f32x4*>(op + 4) = f32x4{x[4], x[5], x[6], x[7]};
+        } else {
+          *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(c_base) + (int64_t)m * p.ldc + n0) = pack8(x);
+        }
+      }
+    }
+  };
+  epi_pass(ic<0>{}); epi_pass(ic<1>{}); epi_pass(ic<2>{}); epi_pass(ic<3>{});
+  epi_pass(ic<4>{}); epi_pass(ic<5>{}); epi_pass(ic<6>{}); epi_pass(ic<7>{});
+}
+
+int gemm4_mode() {         // TC_GEMM4 = 0 never | 1 / unset: the measured rule | 2 whenever the shape allows; read per call (A/B runs)
+  const char* e = getenv("TC_GEMM4");
+  return e ? atoi(e) : 1;
+}
+
+}  // namespace
+
+// Decide whether the four-wave 256x256 kernel takes this (already validated) GEMM, and launch it.  1 = launched (or would be: dry).
+int tc_gemm4_try(const TcGemmParams& p, int batch, hipStream_t s, bool dry) {
+  const int mode = gemm4_mode();
+  if (mode == 0) return 0;
+  if (p.gather != TC_GATHER_LINEAR || p.gn_part || p.a_norm || (p.n & 7) || p.k < 2 * TC_BK) return 0;
+  const bool geglu = p.act == TC_ACT_GEGLU;
+  if (geglu && ((p.n & 31) || p.residual || p.row_bias)) return 0;
+  if ((int64_t)G4_BM * p.lda * 2 >= 0x7fffff00LL || (int64_t)p.n * p.ldw * 2 >= 0x7fffff00LL) return 0;      // 31-bit offsets
+  const int tiles_n = (p.n + G4_BN - 1) / G4_BN, tiles_m = (p.m + G4_BM - 1) / G4_BM;
+  const int64_t total = (int64_t)tiles_n * tiles_m;
+  if (total > 0x3fffffff || batch > 65535) return 0;
+  if (mode == 1) {
+    // the measured rule (profiles/r05_gemm4_bench.txt): TO BE FILLED IN from the first GPU measurement; until then nothing is routed
+    return 0;
+  }
+  if (dry) return 1;
+  dim3 grid((unsigned)total, 1, (unsigned)batch), block(G4_THREADS);
+  if (geglu) hipLaunchKernelGGL(gemm4_kernel<true>, grid, block, 0, s, p, (int)total);
+  else hipLaunchKernelGGL(gemm4_kernel<false>, grid, block, 0, s, p, (int)total);
+  return 1;
+}
