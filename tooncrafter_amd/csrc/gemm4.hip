@@ -11,12 +11,13 @@
 // (fragments of the next K-slice requested before the current slice's MFMAs; tile requests from inline asm between the MFMA
 // rows; one counted wait + one raw barrier per K-step), scaled to 8 x 8 tiles per wave.
 //
-//   per K-step kb (stage st = kb & 1):
-//     fragments of slice 1 of step kb  ->  set 1          | 64 MFMAs of slice 0 (set 0)
-//     s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier            : every wave has read stage st; step kb + 1 has landed in stage st ^ 1
-//     fragments of slice 0 of step kb + 1  ->  set 0      | 64 MFMAs of slice 1 (set 1), the 16 requests of step kb + 2
-//                                                           (into stage st) in pairs between the MFMA rows
-//   A request is waited for one whole K-step (2048 matrix cycles) after it was issued.
+//   per K-step kb (stage st = kb & 1; slice = 32 of the 64 K values; set = 8 + 8 fragments of a slice in registers):
+//     24 MFMAs of slice 0 (set 0) | fragments of slice 1 -> set 1
+//     s_waitcnt lgkmcnt(0); s_barrier  (B1)             : every wave has read all of stage st
+//     40 MFMAs of slice 0 | 8 requests of step kb + 2 (W rows, into stage st)
+//     s_waitcnt vmcnt(8); s_barrier    (B2)             : step kb + 1 has landed in stage st ^ 1, for every wave
+//     64 MFMAs of slice 1 (set 1) | fragments of slice 0 of step kb + 1 -> set 0 | 8 requests of step kb + 2 (A rows)
+//   A request is waited for more than one whole K-step (2048 matrix cycles) after it was issued.
 // LDS: 2 stages x (256 + 256) rows x 128 B = 128 KiB (one block per CU), XOR swizzle (row >> 1) & 7 on the SOURCE chunk of the
 // DMA as everywhere (conflict-free ds_read_b128 of the 16x16x32 operand layout from 16-aligned row blocks).
 // Epilogue: per wave eight passes of one 16-row tile row through a private fp32 slab [16][128 + 4] in the idle stage buffers,
@@ -149,29 +150,65 @@ __global__ __launch_bounds__(G4_THREADS) void gemm4_kernel(const TcGemmParams p,
   read_frags(0, 0, af0, bf0);
   // one K-step; ISSUE: the 16 requests of step kb + 2 go out between the MFMA rows of the second slice.  Two loops (all steps
   // but the last two issue) instead of a run-time condition around every pair of requests: no branches inside a step
+  // MFMA row i of a slice with the requests (if any) of pieces Q0, Q1 behind its fourth and eighth MFMA: six scalar /
+  // vector-memory instructions each, issued in the shadow of the MFMA in flight.  MFMAs and requests are both volatile asm:
+  // this IS the instruction order.
+  auto row = [&](auto I_, const bf16x8 (&af)[G4_NT], const bf16x8 (&bf)[G4_NT], auto Q0_, auto Q1_) {
+    constexpr int i = decltype(I_)::value, q0 = decltype(Q0_)::value, q1 = decltype(Q1_)::value;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g4_mfma(acc[i][j], af[i], bf[j]);
+    if constexpr (q0 >= 0) issue_piece(ic<(q0 >= 0 ? q0 : 0)>{});
+#pragma unroll
+    for (int j = 4; j < 8; ++j) g4_mfma(acc[i][j], af[i], bf[j]);
+    if constexpr (q1 >= 0) issue_piece(ic<(q1 >= 0 ? q1 : 0)>{});
+  };
+  // One K-step, TWO barriers.  B1 sits where every wave has the step's last fragments in registers: from there on stage st is
+  // free and the requests of step kb + 2 go out -- 8 before B2, 8 after it -- so a request is waited for MORE than a whole K-step
+  // after it was issued (with a single barrier at mid-step the last request had half a step: 1024 matrix cycles, less than an
+  // L2 round trip under load).  B2 = step kb + 1 has landed for every wave: the counted wait leaves the 8 newest requests in flight.
   auto kstep = [&](auto ISSUE_, int kb) {
     constexpr bool ISSUE = decltype(ISSUE_)::value != 0;
+    constexpr int N = -1;
     const int st = kb & 1;
-    read_frags(st, 1, af1, bf1);
-    mma_row(ic<0>{}, af0, bf0); mma_row(ic<1>{}, af0, bf0); mma_row(ic<2>{}, af0, bf0); mma_row(ic<3>{}, af0, bf0);
-    mma_row(ic<4>{}, af0, bf0); mma_row(ic<5>{}, af0, bf0); mma_row(ic<6>{}, af0, bf0); mma_row(ic<7>{}, af0, bf0);
-    __builtin_amdgcn_sched_barrier(0);                       // (hipcc otherwise sinks the MFMAs below the wait)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    g8_barrier();                                            // stage st is free, stage st ^ 1 is complete, for every wave
-    if constexpr (ISSUE) prep(kb + 2, st);
+    row(ic<0>{}, af0, bf0, ic<N>{}, ic<N>{});
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(st, 1, af1, bf1);                             // behind the first MFMA row: hipcc's waits in front of that row only see old reads
+    __builtin_amdgcn_sched_barrier(0);
+    row(ic<1>{}, af0, bf0, ic<N>{}, ic<N>{});
+    row(ic<2>{}, af0, bf0, ic<N>{}, ic<N>{});
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    g8_barrier();                                            // B1: stage st has been read by every wave
+    if constexpr (ISSUE) {
+      prep(kb + 2, st);
+      row(ic<3>{}, af0, bf0, ic<0>{}, ic<1>{});
+      row(ic<4>{}, af0, bf0, ic<2>{}, ic<3>{});
+      row(ic<5>{}, af0, bf0, ic<4>{}, ic<5>{});
+      row(ic<6>{}, af0, bf0, ic<6>{}, ic<7>{});
+      row(ic<7>{}, af0, bf0, ic<N>{}, ic<N>{});
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      row(ic<3>{}, af0, bf0, ic<N>{}, ic<N>{}); row(ic<4>{}, af0, bf0, ic<N>{}, ic<N>{}); row(ic<5>{}, af0, bf0, ic<N>{}, ic<N>{});
+      row(ic<6>{}, af0, bf0, ic<N>{}, ic<N>{}); row(ic<7>{}, af0, bf0, ic<N>{}, ic<N>{});
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    g8_barrier();                                            // B2: step kb + 1 is complete in stage st ^ 1
+    row(ic<0>{}, af1, bf1, ic<N>{}, ic<N>{});
+    __builtin_amdgcn_sched_barrier(0);
     read_frags(st ^ 1, 0, af0, bf0);                         // (in the last step it reads a dead stage, nothing uses it)
-    // second slice: after every fourth MFMA one request (six scalar / vector-memory instructions: they issue in the shadow of the
-    // MFMA in flight; the MFMAs and the requests are both volatile asm, so this IS the instruction order)
-    auto row1 = [&](auto I_) {
-      constexpr int i = decltype(I_)::value;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) g4_mfma(acc[i][j], af1[i], bf1[j]);
-      if constexpr (ISSUE) issue_piece(ic<2 * i>{});
-#pragma unroll
-      for (int j = 4; j < 8; ++j) g4_mfma(acc[i][j], af1[i], bf1[j]);
-      if constexpr (ISSUE) issue_piece(ic<2 * i + 1>{});
-    };
-    row1(ic<0>{}); row1(ic<1>{}); row1(ic<2>{}); row1(ic<3>{}); row1(ic<4>{}); row1(ic<5>{}); row1(ic<6>{}); row1(ic<7>{});
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (ISSUE) {
+      row(ic<1>{}, af1, bf1, ic<8>{}, ic<9>{});
+      row(ic<2>{}, af1, bf1, ic<10>{}, ic<11>{});
+      row(ic<3>{}, af1, bf1, ic<12>{}, ic<13>{});
+      row(ic<4>{}, af1, bf1, ic<14>{}, ic<15>{});
+    } else {
+      row(ic<1>{}, af1, bf1, ic<N>{}, ic<N>{}); row(ic<2>{}, af1, bf1, ic<N>{}, ic<N>{});
+      row(ic<3>{}, af1, bf1, ic<N>{}, ic<N>{}); row(ic<4>{}, af1, bf1, ic<N>{}, ic<N>{});
+    }
+    row(ic<5>{}, af1, bf1, ic<N>{}, ic<N>{}); row(ic<6>{}, af1, bf1, ic<N>{}, ic<N>{}); row(ic<7>{}, af1, bf1, ic<N>{}, ic<N>{});
   };
   int kb = 0;
   for (; kb + 2 < nk; ++kb) kstep(ic<1>{}, kb);
