@@ -42,9 +42,9 @@ def _same_within_rounding(new, base, what):
     assert d <= 2.0 ** -6 * max(base.float().abs().max().item(), 1.0), f"{what}: differs from the tiled kernels by {d}"
 
 
-# full tiles, ragged M and N (also below one tile), K tails (k % 64 != 0), K = 2 and 3 steps (prologue / tail loop only), long K
+# full tiles, ragged M and N (also below one tile), K = 2 ... 7 steps of 64 (prologue / tail slices only, the ring wrapping once), long K
 @pytest.mark.parametrize("m,n,k", [(256, 256, 128), (512, 768, 192), (1000, 520, 320), (77, 1280, 640), (5120, 1280, 5120),
-                                   (300, 264, 136), (20480, 640, 2560), (257, 8, 4096), (2048, 2048, 2048)])
+                                   (300, 264, 256), (20480, 640, 2560), (257, 8, 4096), (2048, 2048, 2048), (600, 512, 384), (333, 256, 448)])
 @pytest.mark.parametrize("epi", ["plain", "bias+res", "silu+rowbias"])
 def test_gemm4_linear(hip, emu, m, n, k, epi):
     a, w = rnd(m, k, seed=1), rnd(n, k, seed=2, scale=k ** -0.5)
@@ -61,7 +61,7 @@ def test_gemm4_linear(hip, emu, m, n, k, epi):
     _same_within_rounding(new, base, f"gemm4 {m}x{n}x{k} {epi}")
 
 
-@pytest.mark.parametrize("m,n_out,k", [(20480, 2560, 640), (5120, 5120, 1280), (300, 80, 320), (256, 128, 128)])
+@pytest.mark.parametrize("m,n_out,k", [(20480, 2560, 640), (5120, 5120, 1280), (300, 64, 320), (256, 128, 128)])
 def test_gemm4_geglu(hip, emu, m, n_out, k):
     """The GEGLU projections (weights packed per 32 columns: 16 values | 16 gates): out = (x W_v + b_v) * gelu(x W_g + b_g)."""
     g = torch.Generator().manual_seed(7)
