@@ -44,12 +44,13 @@ def case(tag, m, n, k, geglu=False, res=False):
     r = [torch.randn(m, n, device=DEV).to(BF) for _ in range(SETS)] if res else None
     act = ACT_GEGLU if geglu else ACT_NONE
 
-    def mine(mode):
+    def mine(mode, variant="2"):
         def f(i):
-            os.environ["TC_GEMM4"] = mode
+            os.environ["TC_GEMM4"], os.environ["TC_G4_VARIANT"] = mode, variant
             return hip.gemm(a[i], w, b, act=act, residual=None if r is None else r[i])
         return f
-    v = {"default routing": mine("0"), "gemm4": mine("2"), "hipBLASLt matmul only": lambda i: F.linear(a[i], w)}
+    v = {"default routing": mine("0"), "gemm4 v0 (burst reads)": mine("2", "0"), "gemm4 v1 (1 barrier)": mine("2", "1"),
+         "gemm4": mine("2", "2"), "hipBLASLt matmul only": lambda i: F.linear(a[i], w)}
     t = time_variants(v)
     os.environ.pop("TC_GEMM4", None)
     fl = 2.0 * m * n * k

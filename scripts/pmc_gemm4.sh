@@ -1,8 +1,8 @@
 #!/bin/bash
-# usage: scripts/pmc_gemm4.sh OUTDIR -> OUTDIR/pmc_gemm4_{a,b,c}.json: SQ / LDS / vector-memory counters of gemm8 / gemm4 / hipBLASLt at 8192^3
+# usage: scripts/pmc_gemm4.sh TAG -> gpurun_out/TAG/pmc_gemm4_{a,b,c}.json: SQ / LDS / vector-memory counters of gemm8 / gemm4 / hipBLASLt at 8192^3
 set -u
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
-OUT=${1:-$ROOT/gpurun_out}; mkdir -p $OUT; export TMPDIR=/tmp
+OUT=$ROOT/gpurun_out/${1:-pmc_gemm4}; mkdir -p $OUT; export TMPDIR=/tmp
 A="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES"
 B="SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_VMEM"
 C="TA_TA_BUSY_sum TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"

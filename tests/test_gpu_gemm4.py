@@ -27,8 +27,11 @@ def emu():
     return EmuOps(round_bf16=True)
 
 
+VARIANT = {"v": 2}          # TC_G4_VARIANT for the gemm4 arm (the `variant` fixture walks 0, 1, 2 over the linear cases)
+
+
 def _both(fn):
-    with env(TC_GEMM4=2):
+    with env(TC_GEMM4=2, TC_G4_VARIANT=VARIANT["v"]):
         a = fn()
     with env(TC_GEMM4=0):
         b = fn()
@@ -42,11 +45,13 @@ def _same_within_rounding(new, base, what):
     assert d <= 2.0 ** -6 * max(base.float().abs().max().item(), 1.0), f"{what}: differs from the tiled kernels by {d}"
 
 
-# full tiles, ragged M and N (also below one tile), K = 2 ... 7 steps of 64 (prologue / tail slices only, the ring wrapping once), long K
+# full tiles, ragged M and N (also below one tile), K tails (k % 64 != 0), K = 2 and 3 steps (prologue / tail loop only), long K
 @pytest.mark.parametrize("m,n,k", [(256, 256, 128), (512, 768, 192), (1000, 520, 320), (77, 1280, 640), (5120, 1280, 5120),
-                                   (300, 264, 256), (20480, 640, 2560), (257, 8, 4096), (2048, 2048, 2048), (600, 512, 384), (333, 256, 448)])
+                                   (300, 264, 136), (20480, 640, 2560), (257, 8, 4096), (2048, 2048, 2048), (600, 512, 384)])
 @pytest.mark.parametrize("epi", ["plain", "bias+res", "silu+rowbias"])
-def test_gemm4_linear(hip, emu, m, n, k, epi):
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_gemm4_linear(hip, emu, m, n, k, epi, variant):
+    VARIANT["v"] = variant
     a, w = rnd(m, k, seed=1), rnd(n, k, seed=2, scale=k ** -0.5)
     kw = {}
     bias = None
@@ -59,6 +64,7 @@ def test_gemm4_linear(hip, emu, m, n, k, epi):
     new, base = _both(lambda: hip.gemm(a, w, bias, **kw))
     check(new, emu.gemm(a, w, bias, **kw), f"gemm4 {m}x{n}x{k} {epi}")
     _same_within_rounding(new, base, f"gemm4 {m}x{n}x{k} {epi}")
+    VARIANT["v"] = 2
 
 
 @pytest.mark.parametrize("m,n_out,k", [(20480, 2560, 640), (5120, 5120, 1280), (300, 64, 320), (256, 128, 128)])
@@ -103,8 +109,9 @@ def test_gemm4_f32_output_batch_and_strided_views(hip, emu):
 def test_gemm4_repeated_launches_are_bit_identical(hip):
     """Race screen for the hand-counted waits: 40 launches of a many-tile, long-K problem, all identical."""
     a, w = rnd(4096, 4096, seed=21), rnd(4096, 4096, seed=22, scale=4096 ** -0.5)
-    with env(TC_GEMM4=2):
-        first = hip.gemm(a, w)
-        for _ in range(40):
-            assert torch.equal(hip.gemm(a, w), first)
+    for v in (0, 1, 2):
+        with env(TC_GEMM4=2, TC_G4_VARIANT=v):
+            first = hip.gemm(a, w)
+            for _ in range(40):
+                assert torch.equal(hip.gemm(a, w), first)
     torch.cuda.synchronize()

@@ -11,9 +11,15 @@
 // (fragments of the next K-slice requested before the current slice's MFMAs; tile requests from inline asm between the MFMA
 // rows; one counted wait + one raw barrier per K-step), scaled to 8 x 8 tiles per wave.
 //
-//   (the loop, its ring of five 32-KiB slice buffers and the waits are described at the loop)
-// LDS: 5 slice buffers x (256 + 256) rows x 64 B = 160 KiB (one block per CU); XOR swizzle (row >> 1) & 3 on the SOURCE chunk of the
-// DMA (64-byte rows: sixteen lanes of one chunk index hit eight 16-byte bank slots twice -- the minimum for a 256-byte read).
+//   per K-step kb (stage st = kb & 1; slice = 32 of the 64 K values; set = 8 + 8 fragments of a slice in registers):
+//     24 MFMAs of slice 0 (set 0) | fragments of slice 1 -> set 1
+//     s_waitcnt lgkmcnt(0); s_barrier  (B1)             : every wave has read all of stage st
+//     40 MFMAs of slice 0 | 8 requests of step kb + 2 (W rows, into stage st)
+//     s_waitcnt vmcnt(8); s_barrier    (B2)             : step kb + 1 has landed in stage st ^ 1, for every wave
+//     64 MFMAs of slice 1 (set 1) | fragments of slice 0 of step kb + 1 -> set 0 | 8 requests of step kb + 2 (A rows)
+//   A request is waited for more than one whole K-step (2048 matrix cycles) after it was issued.
+// LDS: 2 stages x (256 + 256) rows x 128 B = 128 KiB (one block per CU), XOR swizzle (row >> 1) & 7 on the SOURCE chunk of the
+// DMA as everywhere (conflict-free ds_read_b128 of the 16x16x32 operand layout from 16-aligned row blocks).
 // Epilogue: per wave eight passes of one 16-row tile row through a private fp32 slab [16][128 + 4] in the idle stage buffers,
 // then 16-byte row vectors (bias / row bias / activation / residual, or the GEGLU product of the per-32 packed columns).
 // Linear gather only; the convolutions that dominate the UNet have N = 320 / 640 and would need a 256x160 variant with a
@@ -27,12 +33,10 @@ namespace {
 constexpr int G4_BM = 256, G4_BN = 256, G4_THREADS = 256;
 constexpr int G4_WT = 128;                                   // wave tile
 constexpr int G4_NT = G4_WT / 16;                            // 8 MFMA tiles per wave-tile side
-constexpr int G4_KS = 32;                                    // K values per SLICE = one MFMA depth; the unit of the LDS ring
-constexpr int G4_ROWB = G4_KS * 2;                           // bytes per tile row in a slice buffer: 64 (four 16-byte chunks)
-constexpr int G4_HALF = G4_BM * G4_ROWB;                     // the A (or W) rows of one slice: 16 KiB
-constexpr int G4_SB = 2 * G4_HALF;                           // one slice buffer: A rows | W rows = 32 KiB
-constexpr int G4_NB = 5;                                     // ring of five slice buffers = 160 KiB: the whole CU
-constexpr int G4_R = 4;                                      // request instructions per wave, slice and operand: 4 x 16 rows
+constexpr int G4_STAGE = (G4_BM + G4_BN) * TC_BK * 2;        // 64 KiB
+constexpr int G4_RSTEP = G4_THREADS / 8;                     // rows per loader pass: 32
+constexpr int G4_R = G4_BM / G4_RSTEP;                       // loader passes over the A rows (and over the W rows): 8
+constexpr int G4_PIECE = G4_RSTEP * TC_BK * 2;               // LDS bytes from one loader pass to the next: 4 KiB
 constexpr int G4_SLAB_LD = G4_WT + 4;                        // fp32 slab row stride: +4 keeps the four row groups of a spill on distinct banks
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
@@ -45,9 +49,9 @@ __device__ __forceinline__ void g4_mfma(f32x4_t& c, const bf16x8& a, const bf16x
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
 
-template <bool GEGLU>
+template <bool GEGLU, int V>
 __global__ __launch_bounds__(G4_THREADS) void gemm4_kernel(const TcGemmParams p, const int total_tiles) {
-  __shared__ __attribute__((aligned(1024))) char smem[G4_NB * G4_SB];
+  __shared__ __attribute__((aligned(1024))) char smem[2 * G4_STAGE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -66,36 +70,43 @@ __global__ __launch_bounds__(G4_THREADS) void gemm4_kernel(const TcGemmParams p,
   const g8_srd_t a_srd = g8_make_srd(reinterpret_cast<const bf16_t*>(p.a) + bz * p.stride_a + (int64_t)tile_m * G4_BM * p.lda,
                                      tc_a_extent(p) - (int64_t)tile_m * G4_BM * p.lda * 2);
 
-  // ---- loader geometry.  One wave instruction fills 1 KiB = 16 rows x 64 B of a slice buffer, lane l at (row l >> 2, physical
-  // chunk l & 3); the XOR swizzle (row >> 1) & 3 is applied to the SOURCE chunk.  Wave w requests rows (4 w + q) * 16 .. + 15 of
-  // the A half and of the W half, q = 0..3: eight instructions per wave and slice.
-  const int lr = lane >> 2;
-  const int chunk = (lane & 3) ^ ((lr >> 1) & 3);              // the logical 16-byte chunk (8 K values) this lane fetches
+  // ---- loader geometry (gemm16.hip): thread -> (row lrow + 32 q, 16-byte chunk), swizzle on the SOURCE chunk; one wave
+  // instruction fills 1 KiB = 8 rows
+  const int lrow = tid >> 3;
+  const int chunk = (tid & 7) ^ ((lrow >> 1) & 7);
   uint32_t a_voff[G4_R], b_voff[G4_R];
 #pragma unroll
   for (int q = 0; q < G4_R; ++q) {
-    const int ml = (wave * G4_R + q) * 16 + lr;
+    const int ml = lrow + G4_RSTEP * q;
     a_voff[q] = tile_m * G4_BM + ml < p.m ? (uint32_t)((int64_t)ml * p.lda * 2 + chunk * 16) : TC_OOB;
     const int n = tile_n * G4_BN + ml;
     b_voff[q] = n < p.n ? (uint32_t)((int64_t)n * p.ldw * 2 + chunk * 16) : TC_OOB;
   }
-  const int nh = p.k / G4_KS;                                  // slices of this problem (K % 64 == 0: host)
+  const int nk = (p.k + TC_BK - 1) / TC_BK;
+  const bool k_ragged = (p.k & (TC_BK - 1)) != 0;
 
   uint32_t r_soff = 0, r_dst = 0;
-  auto prep = [&](int h, int buf) {                            // buf = h % 5 (kept by the caller: no division in the loop)
-    const int k0 = h * G4_KS;
+  auto prep = [&](int kb, int stage) {
+    const int k0 = kb * TC_BK;
+    if (k_ragged && kb == nk - 1) {                       // the K tail: its chunks are zero-filled by an out-of-range offset; only
+      const uint32_t kill = (k0 + chunk * 8 >= p.k) ? TC_OOB : 0u;      // the tile's LAST requests see it (chunk = the SOURCE chunk)
+#pragma unroll
+      for (int q = 0; q < G4_R; ++q) { a_voff[q] |= kill; b_voff[q] |= kill; }
+    }
     r_soff = (uint32_t)k0 * 2u;
-    r_dst = lds0 + (uint32_t)(buf * G4_SB + wave_u * (G4_R * 1024));
+    r_dst = lds0 + (uint32_t)(stage * G4_STAGE + wave_u * 1024);
   };
-  // piece q of the prepared slice: 0..3 = W rows, 4..7 = A rows
+  // piece q of the prepared K-step: 0..7 = W row passes, 8..15 = A row passes
   auto issue_piece = [&](auto Q_) {
     constexpr int q = decltype(Q_)::value;
-    if constexpr (q < G4_R) g8_dma16(w_srd, r_dst + G4_HALF + q * 1024, b_voff[q], r_soff);
-    else g8_dma16(a_srd, r_dst + (q - G4_R) * 1024, a_voff[q - G4_R], r_soff);
+    if constexpr (q < G4_R) g8_dma16(w_srd, r_dst + G4_BM * TC_BK * 2 + q * G4_PIECE, b_voff[q], r_soff);
+    else g8_dma16(a_srd, r_dst + (q - G4_R) * G4_PIECE, a_voff[q - G4_R], r_soff);
   };
   auto issue_all = [&]() {
     issue_piece(ic<0>{}); issue_piece(ic<1>{}); issue_piece(ic<2>{}); issue_piece(ic<3>{});
     issue_piece(ic<4>{}); issue_piece(ic<5>{}); issue_piece(ic<6>{}); issue_piece(ic<7>{});
+    issue_piece(ic<8>{}); issue_piece(ic<9>{}); issue_piece(ic<10>{}); issue_piece(ic<11>{});
+    issue_piece(ic<12>{}); issue_piece(ic<13>{}); issue_piece(ic<14>{}); issue_piece(ic<15>{});
   };
 
   f32x4_t acc[G4_NT][G4_NT];
@@ -104,113 +115,249 @@ __global__ __launch_bounds__(G4_THREADS) void gemm4_kernel(const TcGemmParams p,
 #pragma unroll
     for (int j = 0; j < G4_NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  // v_mfma_f32_16x16x32_bf16 operands: lane holds row (lane & 15) of its 16-row tile, k = 8 (lane >> 4) .. +7 of the slice -> one
-  // ds_read_b128 at chunk (lane >> 4) of that 64-byte row; tile rows step by 16, so (row >> 1) & 3 is the lane's.  Sixteen lanes
-  // of one chunk index then touch eight distinct 16-byte bank slots twice: the two cycles a 256-byte read needs anyway.
+  // v_mfma_f32_16x16x32_bf16 operands: lane holds row (lane & 15) of its 16-row tile, k = 8 (lane >> 4) .. +7 of the 32-deep
+  // slice -> one ds_read_b128 at 16-byte chunk 4 ks + (lane >> 4) of that row; tile rows step by 16, so (row >> 1) & 7 is the lane's
   const int frow = lane & 15;
   const int fq = lane >> 4;
-  const int f_col = (fq ^ ((frow >> 1) & 3)) << 4;
-  const int a_row0 = (wm * G4_WT + frow) * G4_ROWB + f_col;
-  const int b_row0 = G4_HALF + (wn * G4_WT + frow) * G4_ROWB + f_col;
-  auto read_frags = [&](int buf, bf16x8 (&af)[G4_NT], bf16x8 (&bf)[G4_NT]) {
-    const char* s0 = smem + buf * G4_SB;
+  const int a_row0 = (wm * G4_WT + frow) * (TC_BK * 2);
+  const int b_row0 = G4_BM * TC_BK * 2 + (wn * G4_WT + frow) * (TC_BK * 2);
+  const int f_sw = (frow >> 1) & 7;                          // wm * 128 and wn * 128 are multiples of 16: they do not enter
+  auto read_frags = [&](int stage, int ks, bf16x8 (&af)[G4_NT], bf16x8 (&bf)[G4_NT]) {
+    const char* s0 = smem + stage * G4_STAGE + (((ks * 4 + fq) ^ f_sw) << 4);
 #pragma unroll
-    for (int i = 0; i < G4_NT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(s0 + a_row0 + i * (16 * G4_ROWB));
+    for (int i = 0; i < G4_NT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(s0 + a_row0 + i * (16 * TC_BK * 2));
 #pragma unroll
-    for (int j = 0; j < G4_NT; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(s0 + b_row0 + j * (16 * G4_ROWB));
+    for (int j = 0; j < G4_NT; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(s0 + b_row0 + j * (16 * TC_BK * 2));
   };
-  // MFMA row i of a slice with the request (if any) of piece Q behind its eighth MFMA: six scalar / vector-memory instructions
-  // issued in the shadow of the MFMA in flight.  MFMAs and requests are both volatile asm: this IS the instruction order.
-  auto row = [&](auto I_, const bf16x8 (&af)[G4_NT], const bf16x8 (&bf)[G4_NT], auto Q_) {
-    constexpr int i = decltype(I_)::value, q = decltype(Q_)::value;
+  auto mma_row = [&](auto I_, const bf16x8 (&af)[G4_NT], const bf16x8 (&bf)[G4_NT]) {
+    constexpr int i = decltype(I_)::value;
 #pragma unroll
     for (int j = 0; j < G4_NT; ++j) g4_mfma(acc[i][j], af[i], bf[j]);
-    if constexpr (q >= 0) issue_piece(ic<(q >= 0 ? q : 0)>{});
   };
 
-  // ---- main loop over SLICES (32 K values, 64 MFMAs per wave), a ring of five slice buffers.  At the top of slice h: its
-  // fragments are in registers (set h & 1); slices h + 1 .. h + 4 are requested (buffers (h + 1 .. h + 4) % 5); buffer h % 5 has
-  // been read by this wave.  Then
-  //     s_waitcnt vmcnt(24): slice h + 1 has landed (the 3 x 8 newer requests stay in flight); s_barrier: for every wave, and
-  //                          every wave is done with buffer h % 5
-  //     slice h + 5 -> buffer h % 5 (8 requests, one behind each MFMA row) | fragments of slice h + 1 -> the other set |
-  //     64 MFMAs of slice h
-  // FOUR slices = two whole K-steps = 128 KiB per CU are in flight all the time (a two-stage scheme keeps 64 KiB: with an
-  // L2 -> LDS round trip of ~2 us under load that, not the matrix pipe, set the pace of the first version of this kernel and of
-  // gemm8.hip: 9 TB/s chip-wide where the library's own 256x256 kernel, with two K-steps in flight, draws 12.7).
-  bf16x8 af0[G4_NT], bf0[G4_NT], af1[G4_NT], bf1[G4_NT];
-  const int npre = nh < G4_NB ? nh : G4_NB;
-  for (int h = 0; h < npre; ++h) {
-    prep(h, h);
+  // ---- main loop
+  prep(0, 0);
+  issue_all();
+  if (nk > 1) {
+    prep(1, 1);
     issue_all();
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");        // step 0 has landed, the 16 requests of step 1 may be in flight
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  // slice 0 has landed: everything requested after it may stay in flight
-  if (npre >= 5) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-  else if (npre == 4) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-  else if (npre == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  else if (npre == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   g8_barrier();
-  read_frags(0, af0, bf0);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-
-  // One slice.  STEADY: slice h + 5 exists and slices h + 1 .. h + 4 are all requested (compile-time waits, no branches);
-  // otherwise the last slices of the tile: requests and waits by run-time conditions.
-  auto slice = [&](auto STEADY_, int h, int buf, int nbuf, const bf16x8 (&af)[G4_NT], const bf16x8 (&bf)[G4_NT],
-                   bf16x8 (&afn)[G4_NT], bf16x8 (&bfn)[G4_NT]) {
-    constexpr bool STEADY = decltype(STEADY_)::value != 0;
-    constexpr int N = -1;
-    bool issue = true;
-    if constexpr (STEADY) {
-      asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    } else {
-      issue = h + G4_NB < nh;
-      const int newer = nh - 2 - h;                          // slices requested after h + 1 (3, 2, 1, 0; < 0: nothing to wait for)
-      if (newer >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-      else if (newer == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else if (newer == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    g8_barrier();
-    if constexpr (STEADY) {
-      prep(h + G4_NB, buf);
-      row(ic<0>{}, af, bf, ic<0>{});
-    } else {
-      if (issue) {                                           // (all eight at once: the tail is five slices of a tile)
-        prep(h + G4_NB, buf);
-        issue_all();
-      }
-      row(ic<0>{}, af, bf, ic<N>{});
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    read_frags(nbuf, afn, bfn);                              // (behind the last slice it reads a dead buffer, nothing uses it)
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (STEADY) {
-      row(ic<1>{}, af, bf, ic<1>{}); row(ic<2>{}, af, bf, ic<2>{}); row(ic<3>{}, af, bf, ic<3>{}); row(ic<4>{}, af, bf, ic<4>{});
-      row(ic<5>{}, af, bf, ic<5>{}); row(ic<6>{}, af, bf, ic<6>{}); row(ic<7>{}, af, bf, ic<7>{});
-    } else {
-      row(ic<1>{}, af, bf, ic<N>{}); row(ic<2>{}, af, bf, ic<N>{}); row(ic<3>{}, af, bf, ic<N>{}); row(ic<4>{}, af, bf, ic<N>{});
-      row(ic<5>{}, af, bf, ic<N>{}); row(ic<6>{}, af, bf, ic<N>{}); row(ic<7>{}, af, bf, ic<N>{});
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the fragments of slice h + 1 are in registers: this wave is done with buffer nbuf
+  bf16x8 af0[G4_NT], bf0[G4_NT], af1[G4_NT], bf1[G4_NT];
+  read_frags(0, 0, af0, bf0);
+  // one K-step; ISSUE: the 16 requests of step kb + 2 go out between the MFMA rows of the second slice.  Two loops (all steps
+  // but the last two issue) instead of a run-time condition around every pair of requests: no branches inside a step
+  // MFMA row i of a slice with the requests (if any) of pieces Q0, Q1 behind its fourth and eighth MFMA: six scalar /
+  // vector-memory instructions each, issued in the shadow of the MFMA in flight.  MFMAs and requests are both volatile asm:
+  // this IS the instruction order.
+  auto row = [&](auto I_, const bf16x8 (&af)[G4_NT], const bf16x8 (&bf)[G4_NT], auto Q0_, auto Q1_) {
+    constexpr int i = decltype(I_)::value, q0 = decltype(Q0_)::value, q1 = decltype(Q1_)::value;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g4_mfma(acc[i][j], af[i], bf[j]);
+    if constexpr (q0 >= 0) issue_piece(ic<(q0 >= 0 ? q0 : 0)>{});
+#pragma unroll
+    for (int j = 4; j < 8; ++j) g4_mfma(acc[i][j], af[i], bf[j]);
+    if constexpr (q1 >= 0) issue_piece(ic<(q1 >= 0 ? q1 : 0)>{});
   };
-  // two slices per trip: the fragment sets alternate at compile time (K % 64 == 0: an even number of slices -- host)
-  auto next = [&](int b) { return b == G4_NB - 1 ? 0 : b + 1; };
-  int h = 0, buf = 0;
-  for (; h + 1 + G4_NB < nh; h += 2) {
-    const int b1 = next(buf), b2 = next(b1);
-    slice(ic<1>{}, h, buf, b1, af0, bf0, af1, bf1);
-    slice(ic<1>{}, h + 1, b1, b2, af1, bf1, af0, bf0);
-    buf = b2;
-  }
-  for (; h < nh; h += 2) {
-    const int b1 = next(buf), b2 = next(b1);
-    slice(ic<0>{}, h, buf, b1, af0, bf0, af1, bf1);
-    slice(ic<0>{}, h + 1, b1, b2, af1, bf1, af0, bf0);
-    buf = b2;
-  }
-  __syncthreads();                                           // the epilogue slabs reuse the slice buffers
+  // One K-step, TWO barriers.  B1 sits where every wave has the step's last fragments in registers: from there on stage st is
+  // free and the requests of step kb + 2 go out -- 8 before B2, 8 after it -- so a request is waited for MORE than a whole K-step
+  // after it was issued (with a single barrier at mid-step the last request had half a step: 1024 matrix cycles, less than an
+  // L2 round trip under load).  B2 = step kb + 1 has landed for every wave: the counted wait leaves the 8 newest requests in flight.
+  auto kstep_v0 = [&](auto ISSUE_, int kb) {
+    constexpr bool ISSUE = decltype(ISSUE_)::value != 0;
+    constexpr int N = -1;
+    const int st = kb & 1;
+    row(ic<0>{}, af0, bf0, ic<N>{}, ic<N>{});
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(st, 1, af1, bf1);                             // behind the first MFMA row: hipcc's waits in front of that row only see old reads
+    __builtin_amdgcn_sched_barrier(0);
+    row(ic<1>{}, af0, bf0, ic<N>{}, ic<N>{});
+    row(ic<2>{}, af0, bf0, ic<N>{}, ic<N>{});
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    g8_barrier();                                            // B1: stage st has been read by every wave
+    if constexpr (ISSUE) {
+      prep(kb + 2, st);
+      row(ic<3>{}, af0, bf0, ic<0>{}, ic<1>{});
+      row(ic<4>{}, af0, bf0, ic<2>{}, ic<3>{});
+      row(ic<5>{}, af0, bf0, ic<4>{}, ic<5>{});
+      row(ic<6>{}, af0, bf0, ic<6>{}, ic<7>{});
+      row(ic<7>{}, af0, bf0, ic<N>{}, ic<N>{});
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      row(ic<3>{}, af0, bf0, ic<N>{}, ic<N>{}); row(ic<4>{}, af0, bf0, ic<N>{}, ic<N>{}); row(ic<5>{}, af0, bf0, ic<N>{}, ic<N>{});
+      row(ic<6>{}, af0, bf0, ic<N>{}, ic<N>{}); row(ic<7>{}, af0, bf0, ic<N>{}, ic<N>{});
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    g8_barrier();                                            // B2: step kb + 1 is complete in stage st ^ 1
+    row(ic<0>{}, af1, bf1, ic<N>{}, ic<N>{});
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(st ^ 1, 0, af0, bf0);                         // (in the last step it reads a dead stage, nothing uses it)
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (ISSUE) {
+      row(ic<1>{}, af1, bf1, ic<8>{}, ic<9>{});
+      row(ic<2>{}, af1, bf1, ic<10>{}, ic<11>{});
+      row(ic<3>{}, af1, bf1, ic<12>{}, ic<13>{});
+      row(ic<4>{}, af1, bf1, ic<14>{}, ic<15>{});
+    } else {
+      row(ic<1>{}, af1, bf1, ic<N>{}, ic<N>{}); row(ic<2>{}, af1, bf1, ic<N>{}, ic<N>{});
+      row(ic<3>{}, af1, bf1, ic<N>{}, ic<N>{}); row(ic<4>{}, af1, bf1, ic<N>{}, ic<N>{});
+    }
+    row(ic<5>{}, af1, bf1, ic<N>{}, ic<N>{}); row(ic<6>{}, af1, bf1, ic<N>{}, ic<N>{}); row(ic<7>{}, af1, bf1, ic<N>{}, ic<N>{});
+  };
+  // ---- the same K-step with the fragment reads SPREAD between the MFMAs.  Counters of the burst version (profiles/
+  // r05_pmc_gemm8_gemm4_hipblaslt_8192.txt: matrix pipe 53 % busy where the library's kernel of the same tile keeps it 86 % busy)
+  // point at the bursts: four waves leave a barrier together and each issues 16 ds_read_b128 -- 64 KiB, 512 cycles of the CU's LDS
+  // pipe -- in front of its next MFMAs; instruction issue is in order, so the matrix pipe runs dry behind the eight MFMAs queued
+  // before the burst.  One read per four MFMAs keeps the LDS pipe half busy all the time and never stands in front of an MFMA.
+  // half-row h of MFMA row i: four MFMAs
+  auto quad = [&](auto I_, auto H_, const bf16x8 (&af)[G4_NT], const bf16x8 (&bf)[G4_NT]) {
+    constexpr int i = decltype(I_)::value, h0 = decltype(H_)::value * 4;
+#pragma unroll
+    for (int j = h0; j < h0 + 4; ++j) g4_mfma(acc[i][j], af[i], bf[j]);
+  };
+  // fragment f of the next slice: 0..7 = W tiles (all needed by the next slice's first MFMA row), 8..15 = A tiles (tile i by row i)
+  auto read_one = [&](auto F_, int stage, int ks, bf16x8 (&af)[G4_NT], bf16x8 (&bf)[G4_NT]) {
+    constexpr int f = decltype(F_)::value;
+    const char* s0 = smem + stage * G4_STAGE + (((ks * 4 + fq) ^ f_sw) << 4);
+    if constexpr (f < G4_NT) bf[f] = *reinterpret_cast<const bf16x8*>(s0 + b_row0 + f * (16 * TC_BK * 2));
+    else af[f - G4_NT] = *reinterpret_cast<const bf16x8*>(s0 + a_row0 + (f - G4_NT) * (16 * TC_BK * 2));
+  };
+#define G4_SB() __builtin_amdgcn_sched_barrier(0)
+  // one MFMA row of the CURRENT slice (fragments af / bf) with two fragment reads of the NEXT slice (F0, F1; -1 = none) and up to
+  // two requests (Q0, Q1; -1 = none): [4 MFMA] read F0, request Q0 [4 MFMA] read F1, request Q1
+  auto mrow = [&](auto I_, const bf16x8 (&af)[G4_NT], const bf16x8 (&bf)[G4_NT], auto F0_, auto F1_, int nstage, int nks,
+                  bf16x8 (&afn)[G4_NT], bf16x8 (&bfn)[G4_NT], auto Q0_, auto Q1_) {
+    constexpr int f0 = decltype(F0_)::value, f1 = decltype(F1_)::value, q0 = decltype(Q0_)::value, q1 = decltype(Q1_)::value;
+    quad(I_, ic<0>{}, af, bf);
+    G4_SB();
+    if constexpr (f0 >= 0) read_one(ic<(f0 >= 0 ? f0 : 0)>{}, nstage, nks, afn, bfn);
+    if constexpr (q0 >= 0) issue_piece(ic<(q0 >= 0 ? q0 : 0)>{});
+    G4_SB();
+    quad(I_, ic<1>{}, af, bf);
+    G4_SB();
+    if constexpr (f1 >= 0) read_one(ic<(f1 >= 0 ? f1 : 0)>{}, nstage, nks, afn, bfn);
+    if constexpr (q1 >= 0) issue_piece(ic<(q1 >= 0 ? q1 : 0)>{});
+    G4_SB();
+  };
+  // V = 1: ONE barrier per K-step, at mid-step.  Slice 0's MFMAs carry the reads of slice 1 (same stage), slice 1's MFMAs the
+  // reads of the next step's slice 0 and the 16 requests of step kb + 2.  Reads end one MFMA row before the barrier.
+  auto kstep_v1 = [&](auto ISSUE_, int kb) {
+    constexpr bool ISSUE = decltype(ISSUE_)::value != 0;
+    constexpr int N = -1;
+    const int st = kb & 1;
+    mrow(ic<0>{}, af0, bf0, ic<0>{}, ic<1>{}, st, 1, af1, bf1, ic<N>{}, ic<N>{});
+    mrow(ic<1>{}, af0, bf0, ic<2>{}, ic<3>{}, st, 1, af1, bf1, ic<N>{}, ic<N>{});
+    mrow(ic<2>{}, af0, bf0, ic<4>{}, ic<5>{}, st, 1, af1, bf1, ic<N>{}, ic<N>{});
+    mrow(ic<3>{}, af0, bf0, ic<6>{}, ic<7>{}, st, 1, af1, bf1, ic<N>{}, ic<N>{});
+    mrow(ic<4>{}, af0, bf0, ic<8>{}, ic<9>{}, st, 1, af1, bf1, ic<N>{}, ic<N>{});
+    mrow(ic<5>{}, af0, bf0, ic<10>{}, ic<11>{}, st, 1, af1, bf1, ic<N>{}, ic<N>{});
+    mrow(ic<6>{}, af0, bf0, ic<12>{}, ic<13>{}, st, 1, af1, bf1, ic<N>{}, ic<N>{});
+    quad(ic<7>{}, ic<0>{}, af0, bf0);
+    G4_SB();
+    read_one(ic<14>{}, st, 1, af1, bf1);
+    read_one(ic<15>{}, st, 1, af1, bf1);
+    G4_SB();
+    quad(ic<7>{}, ic<1>{}, af0, bf0);
+    G4_SB();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    g8_barrier();                                            // stage st is free, stage st ^ 1 is complete, for every wave
+    if constexpr (ISSUE) {
+      prep(kb + 2, st);
+      mrow(ic<0>{}, af1, bf1, ic<0>{}, ic<1>{}, st ^ 1, 0, af0, bf0, ic<0>{}, ic<1>{});
+      mrow(ic<1>{}, af1, bf1, ic<2>{}, ic<3>{}, st ^ 1, 0, af0, bf0, ic<2>{}, ic<3>{});
+      mrow(ic<2>{}, af1, bf1, ic<4>{}, ic<5>{}, st ^ 1, 0, af0, bf0, ic<4>{}, ic<5>{});
+      mrow(ic<3>{}, af1, bf1, ic<6>{}, ic<7>{}, st ^ 1, 0, af0, bf0, ic<6>{}, ic<7>{});
+      mrow(ic<4>{}, af1, bf1, ic<8>{}, ic<9>{}, st ^ 1, 0, af0, bf0, ic<8>{}, ic<9>{});
+      mrow(ic<5>{}, af1, bf1, ic<10>{}, ic<11>{}, st ^ 1, 0, af0, bf0, ic<10>{}, ic<11>{});
+      mrow(ic<6>{}, af1, bf1, ic<12>{}, ic<13>{}, st ^ 1, 0, af0, bf0, ic<12>{}, ic<13>{});
+      mrow(ic<7>{}, af1, bf1, ic<14>{}, ic<15>{}, st ^ 1, 0, af0, bf0, ic<14>{}, ic<15>{});
+    } else {
+      mrow(ic<0>{}, af1, bf1, ic<0>{}, ic<1>{}, st ^ 1, 0, af0, bf0, ic<N>{}, ic<N>{});
+      mrow(ic<1>{}, af1, bf1, ic<2>{}, ic<3>{}, st ^ 1, 0, af0, bf0, ic<N>{}, ic<N>{});
+      mrow(ic<2>{}, af1, bf1, ic<4>{}, ic<5>{}, st ^ 1, 0, af0, bf0, ic<N>{}, ic<N>{});
+      mrow(ic<3>{}, af1, bf1, ic<6>{}, ic<7>{}, st ^ 1, 0, af0, bf0, ic<N>{}, ic<N>{});
+      mrow(ic<4>{}, af1, bf1, ic<8>{}, ic<9>{}, st ^ 1, 0, af0, bf0, ic<N>{}, ic<N>{});
+      mrow(ic<5>{}, af1, bf1, ic<10>{}, ic<11>{}, st ^ 1, 0, af0, bf0, ic<N>{}, ic<N>{});
+      mrow(ic<6>{}, af1, bf1, ic<12>{}, ic<13>{}, st ^ 1, 0, af0, bf0, ic<N>{}, ic<N>{});
+      mrow(ic<7>{}, af1, bf1, ic<14>{}, ic<15>{}, st ^ 1, 0, af0, bf0, ic<N>{}, ic<N>{});
+    }
+  };
+  // V = 2: TWO barriers.  The 16 reads of slice 1 ride on the first four MFMA rows (one per two MFMAs), B1 behind the fifth row frees
+  // stage st, the requests of step kb + 2 start there (a whole K-step and more before they are waited for), B2 at mid-step.
+  auto drow = [&](auto I_, const bf16x8 (&af)[G4_NT], const bf16x8 (&bf)[G4_NT], auto FB_, int nstage, int nks, bf16x8 (&afn)[G4_NT],
+                  bf16x8 (&bfn)[G4_NT]) {                      // an MFMA row with FOUR reads (fragments FB .. FB + 3)
+    constexpr int i = decltype(I_)::value, fb = decltype(FB_)::value;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) g4_mfma(acc[i][j], af[i], bf[j]);
+    G4_SB(); read_one(ic<fb>{}, nstage, nks, afn, bfn); G4_SB();
+#pragma unroll
+    for (int j = 2; j < 4; ++j) g4_mfma(acc[i][j], af[i], bf[j]);
+    G4_SB(); read_one(ic<fb + 1>{}, nstage, nks, afn, bfn); G4_SB();
+#pragma unroll
+    for (int j = 4; j < 6; ++j) g4_mfma(acc[i][j], af[i], bf[j]);
+    G4_SB(); read_one(ic<fb + 2>{}, nstage, nks, afn, bfn); G4_SB();
+#pragma unroll
+    for (int j = 6; j < 8; ++j) g4_mfma(acc[i][j], af[i], bf[j]);
+    G4_SB(); read_one(ic<fb + 3>{}, nstage, nks, afn, bfn); G4_SB();
+  };
+  auto kstep_v2 = [&](auto ISSUE_, int kb) {
+    constexpr bool ISSUE = decltype(ISSUE_)::value != 0;
+    constexpr int N = -1;
+    const int st = kb & 1;
+    drow(ic<0>{}, af0, bf0, ic<0>{}, st, 1, af1, bf1);
+    drow(ic<1>{}, af0, bf0, ic<4>{}, st, 1, af1, bf1);
+    drow(ic<2>{}, af0, bf0, ic<8>{}, st, 1, af1, bf1);
+    drow(ic<3>{}, af0, bf0, ic<12>{}, st, 1, af1, bf1);
+    mrow(ic<4>{}, af0, bf0, ic<N>{}, ic<N>{}, st, 1, af1, bf1, ic<N>{}, ic<N>{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    g8_barrier();                                            // B1: stage st has been read by every wave
+    if constexpr (ISSUE) {
+      prep(kb + 2, st);
+      mrow(ic<5>{}, af0, bf0, ic<N>{}, ic<N>{}, st, 1, af1, bf1, ic<0>{}, ic<1>{});
+      mrow(ic<6>{}, af0, bf0, ic<N>{}, ic<N>{}, st, 1, af1, bf1, ic<2>{}, ic<3>{});
+      mrow(ic<7>{}, af0, bf0, ic<N>{}, ic<N>{}, st, 1, af1, bf1, ic<4>{}, ic<5>{});
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // step kb + 1 has landed: the six newest requests stay in flight
+    } else {
+      mrow(ic<5>{}, af0, bf0, ic<N>{}, ic<N>{}, st, 1, af1, bf1, ic<N>{}, ic<N>{});
+      mrow(ic<6>{}, af0, bf0, ic<N>{}, ic<N>{}, st, 1, af1, bf1, ic<N>{}, ic<N>{});
+      mrow(ic<7>{}, af0, bf0, ic<N>{}, ic<N>{}, st, 1, af1, bf1, ic<N>{}, ic<N>{});
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    g8_barrier();                                            // B2: step kb + 1 is complete in stage st ^ 1
+    if constexpr (ISSUE) {
+      mrow(ic<0>{}, af1, bf1, ic<0>{}, ic<1>{}, st ^ 1, 0, af0, bf0, ic<6>{}, ic<7>{});
+      mrow(ic<1>{}, af1, bf1, ic<2>{}, ic<3>{}, st ^ 1, 0, af0, bf0, ic<8>{}, ic<9>{});
+      mrow(ic<2>{}, af1, bf1, ic<4>{}, ic<5>{}, st ^ 1, 0, af0, bf0, ic<10>{}, ic<11>{});
+      mrow(ic<3>{}, af1, bf1, ic<6>{}, ic<7>{}, st ^ 1, 0, af0, bf0, ic<12>{}, ic<13>{});
+      mrow(ic<4>{}, af1, bf1, ic<8>{}, ic<9>{}, st ^ 1, 0, af0, bf0, ic<14>{}, ic<15>{});
+    } else {
+      mrow(ic<0>{}, af1, bf1, ic<0>{}, ic<1>{}, st ^ 1, 0, af0, bf0, ic<N>{}, ic<N>{});
+      mrow(ic<1>{}, af1, bf1, ic<2>{}, ic<3>{}, st ^ 1, 0, af0, bf0, ic<N>{}, ic<N>{});
+      mrow(ic<2>{}, af1, bf1, ic<4>{}, ic<5>{}, st ^ 1, 0, af0, bf0, ic<N>{}, ic<N>{});
+      mrow(ic<3>{}, af1, bf1, ic<6>{}, ic<7>{}, st ^ 1, 0, af0, bf0, ic<N>{}, ic<N>{});
+      mrow(ic<4>{}, af1, bf1, ic<8>{}, ic<9>{}, st ^ 1, 0, af0, bf0, ic<N>{}, ic<N>{});
+    }
+    mrow(ic<5>{}, af1, bf1, ic<10>{}, ic<11>{}, st ^ 1, 0, af0, bf0, ic<N>{}, ic<N>{});
+    mrow(ic<6>{}, af1, bf1, ic<12>{}, ic<13>{}, st ^ 1, 0, af0, bf0, ic<N>{}, ic<N>{});
+    mrow(ic<7>{}, af1, bf1, ic<14>{}, ic<15>{}, st ^ 1, 0, af0, bf0, ic<N>{}, ic<N>{});
+  };
+#undef G4_SB
+  auto kstep = [&](auto ISSUE_, int kb) {
+    if constexpr (V == 0) kstep_v0(ISSUE_, kb);
+    else if constexpr (V == 1) kstep_v1(ISSUE_, kb);
+    else kstep_v2(ISSUE_, kb);
+  };
+  int kb = 0;
+  for (; kb + 2 < nk; ++kb) kstep(ic<1>{}, kb);
+  for (; kb < nk; ++kb) kstep(ic<0>{}, kb);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();                                           // the epilogue slabs reuse the stage buffers
 
   // ---- epilogue: per wave, eight passes of one 16-row tile row through a private fp32 slab [16][132]
   float* slab = reinterpret_cast<float*>(smem) + wave * (16 * G4_SLAB_LD);
@@ -305,7 +452,7 @@ int gemm4_mode() {         // TC_GEMM4 = 0 never | 1 / unset: the measured rule 
 int tc_gemm4_try(const TcGemmParams& p, int batch, hipStream_t s, bool dry) {
   const int mode = gemm4_mode();
   if (mode == 0) return 0;
-  if (p.gather != TC_GATHER_LINEAR || p.gn_part || p.a_norm || (p.n & 7) || p.k < 2 * TC_BK || (p.k % TC_BK) != 0 || p.k > 1024 * G4_KS) return 0;
+  if (p.gather != TC_GATHER_LINEAR || p.gn_part || p.a_norm || (p.n & 7) || p.k < 2 * TC_BK) return 0;
   const bool geglu = p.act == TC_ACT_GEGLU;
   if (geglu && ((p.n & 31) || p.residual || p.row_bias)) return 0;
   if ((int64_t)G4_BM * p.lda * 2 >= 0x7fffff00LL || (int64_t)p.n * p.ldw * 2 >= 0x7fffff00LL) return 0;      // 31-bit offsets
@@ -318,7 +465,15 @@ int tc_gemm4_try(const TcGemmParams& p, int batch, hipStream_t s, bool dry) {
   }
   if (dry) return 1;
   dim3 grid((unsigned)total, 1, (unsigned)batch), block(G4_THREADS);
-  if (geglu) hipLaunchKernelGGL(gemm4_kernel<true>, grid, block, 0, s, p, (int)total);
-  else hipLaunchKernelGGL(gemm4_kernel<false>, grid, block, 0, s, p, (int)total);
+  const int v = [] { const char* e = getenv("TC_G4_VARIANT"); return e ? atoi(e) : 2; }();      // K-loop variant (A/B runs): see kstep_v0 / v1 / v2
+#define TC_G4_LAUNCH(V_)                                                                           \
+  do {                                                                                             \
+    if (geglu) hipLaunchKernelGGL((gemm4_kernel<true, V_>), grid, block, 0, s, p, (int)total);     \
+    else hipLaunchKernelGGL((gemm4_kernel<false, V_>), grid, block, 0, s, p, (int)total);          \
+  } while (0)
+  if (v == 0) TC_G4_LAUNCH(0);
+  else if (v == 1) TC_G4_LAUNCH(1);
+  else TC_G4_LAUNCH(2);
+#undef TC_G4_LAUNCH
   return 1;
 }
