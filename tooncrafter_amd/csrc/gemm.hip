@@ -408,7 +408,6 @@ extern "C" int tc_gemm_gn_rows(const TcGemmParams* pp) {
   if (const char* e = getenv("TC_GN_PART")) { if (e[0] == '0') return 0; }    // A/B switch: never emit
   if (tc_gemm_ws_try(p, batch, nullptr, true)) return 0;
   if (tc_conv_halo_try(p, batch, nullptr, true) != 0) return 0;
-  if (tc_gemm4_try(p, batch, nullptr, true)) return 0;
   if (tc_gemm8_try(p, batch, nullptr, true)) return 0;
   if (tc_gemm_tile16_try(p, batch, nullptr, true)) return 160;
   if (tc_gemm_wide_try(p, batch, nullptr, false, true)) return 0;
@@ -486,10 +485,6 @@ extern "C" int tc_gemm_bf16(const TcGemmParams* pp, void* stream) {
       TC_LAUNCH_CHECK();
       return TC_OK;
     }
-  }
-  if (force == 0 && tc_gemm4_try(p, batch, s)) {                       // linear problems that fill 256x256 tiles: four waves, 128x128 each
-    TC_LAUNCH_CHECK();
-    return TC_OK;
   }
   if (force == 0 && tc_gemm8_try(p, batch, s)) {                       // long-K / wide-N problems: 8-wave 256x256 ping-pong
     TC_LAUNCH_CHECK();
