@@ -15,7 +15,8 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 from tooncrafter_amd import ops  # noqa: E402
 
-ENV_KEYS = ("TC_GEMM_TILE", "TC_GEMM_TILE16", "TC_GEMM_WS", "TC_GEMM_PIPE", "TC_GEMM_SPLITK", "TC_GEMM_WIDE")
+ENV_KEYS = ("TC_GEMM_TILE", "TC_GEMM_TILE16", "TC_GEMM_WS", "TC_GEMM_PIPE", "TC_GEMM_SPLITK", "TC_GEMM_WIDE", "TC_GEMM8", "TC_CONV_HALO",
+            "TC_CONV_HALO_TALL", "TC_CONV_HALO_KSPLIT", "TC_G16_ILV", "TC_G16_TALL")
 VARIANTS = [("default", {}),
             ("default, plain K loop", {"TC_GEMM_PIPE": "0"}),
             ("128x128", {"TC_GEMM_TILE": "22", "TC_GEMM_TILE16": "0", "TC_GEMM_WS": "0"}),
@@ -30,7 +31,16 @@ VARIANTS = [("default", {}),
             ("no split-K", {"TC_GEMM_SPLITK": "0"}),
             ("split-K 2", {"TC_GEMM_SPLITK": "2"}),
             ("split-K 4", {"TC_GEMM_SPLITK": "4"}),
-            ("split-K 8", {"TC_GEMM_SPLITK": "8"})]
+            ("split-K 8", {"TC_GEMM_SPLITK": "8"}),
+            # round 4 / 5 kernels (a tile-family switch also sends the 3x3 convolutions back to the implicit GEMM: conv_halo.hip)
+            ("8-wave 256x256", {"TC_GEMM8": "2"}),
+            ("no 8-wave", {"TC_GEMM8": "0"}),
+            ("160x160, plain loop", {"TC_GEMM_TILE16": "2", "TC_GEMM_WS": "0", "TC_G16_ILV": "0"}),
+            ("160x160, loop 2", {"TC_GEMM_TILE16": "2", "TC_GEMM_WS": "0", "TC_G16_ILV": "2"}),
+            ("halo patches off", {"TC_CONV_HALO": "0"}),
+            ("halo, tall patches", {"TC_CONV_HALO_TALL": "1"}),
+            ("halo, K split always", {"TC_CONV_HALO_KSPLIT": "2"}),
+            ("halo, no K split", {"TC_CONV_HALO_KSPLIT": "0"})]
 
 
 def set_env(env):
