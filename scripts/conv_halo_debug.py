@@ -2,7 +2,7 @@
 """Where is it wrong?  Localises a mismatch of the tap-reuse convolution kernel (csrc/conv_halo.hip) against the fp32
 statement of the operator, for the FIRST GPU session with that kernel (it was written without one):
 
-  python scripts/conv_halo_debug.py [3x3|t3] [frames h w cin n] [tall|ksplit|gn]
+  python scripts/conv_halo_debug.py [3x3|t3] [frames h w cin n] [tall|ksplit]
 
 1. the whole problem on random data: error by patch position (y, x), by frame / clip, by 16-column block;
 2. ONE TAP at a time (all other taps' weights zero): a wrong tap offset / padding mask shows up as that tap alone;
@@ -27,8 +27,6 @@ taps = 9 if kind == "3x3" else 3
 os.environ["TC_CONV_HALO"] = "2"
 os.environ["TC_CONV_HALO_TALL"] = "2" if "tall" in flags else "0"
 os.environ["TC_CONV_HALO_KSPLIT"] = "2" if "ksplit" in flags else "0"
-if "gn" in flags:
-    os.environ["TC_GN_FUSE"] = "1"
 hip, emu = HipOps(), EmuOps(round_bf16=True)
 dev, BF = "cuda", torch.bfloat16
 m = frames * h * w_
@@ -37,13 +35,9 @@ conv = dict(kind="3x3", frames=frames, cin=cin, h_in=h, w_in=w_, h_out=h, w_out=
 g = torch.Generator().manual_seed(0)
 x = torch.randn(m, cin, generator=g).to(BF).to(dev)
 wt = (torch.randn(n, taps * cin, generator=g) * (taps * cin) ** -0.5).to(BF).to(dev)
-gamma, beta = (torch.rand(cin, generator=g) + 0.5).to(dev), (torch.randn(cin, generator=g) + 2.0).to(dev)
-gnkw = dict(samples=frames if kind == "3x3" else frames // 16, rows=h * w_ if kind == "3x3" else 16 * h * w_, eps=1e-5)
 
 
 def run(xx, ww):
-    if "gn" in flags:
-        return hip.gn_conv(xx, gamma, beta, ww, conv=conv, **gnkw).float(), emu.gn_conv(xx, gamma, beta, ww, conv=conv, **gnkw).float()
     return hip.gemm(xx, ww, conv=conv).float(), emu.gemm(xx, ww, conv=conv).float()
 
 
