@@ -467,6 +467,30 @@ def other_binding_clip(args):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
+def host_handover(device, ms_per_clip):
+    """What a caller that starts from HOST buffers adds to a clip: the two endpoint frames in (fp32 [1, 3, 2, 320, 512],
+    pageable, like the reference's `videos.to("cuda")`, inference.py:223) and the uint8 clip out ([1, 16, 320, 512, 3],
+    the f4 output path).  `value` is quoted with inputs resident in HBM; this is the PCIe-inclusive figure beside it."""
+    try:
+        frames = torch.randn(1, 3, 2, 320, 512)
+        clip = torch.zeros((1, 16, 320, 512, 3), dtype=torch.uint8, device=device)
+
+        def wall(fn, reps=5):
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / reps * 1e3
+        h2d, d2h = wall(lambda: frames.to(device)), wall(lambda: clip.cpu())
+        return {"frames_in_h2d_ms": round(h2d, 3), "clip_u8_out_d2h_ms": round(d2h, 3),
+                "bytes_in": frames.numel() * 4, "bytes_out": clip.numel(),
+                "frames_per_s_pcie_inclusive": round(16.0 / ((ms_per_clip + h2d + d2h) * 1e-3), 4)}
+    except Exception as e:                                       # noqa: BLE001  (an extra must never cost the headline)
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
 def measure_boundary(model, inp):
     """The boundary question (ctypes + hipGraph vs a per-op extension): wall time of ONE B=2 UNet forward and of
     ONE 16-frame decode, launched eagerly through ctypes (~1130 / ~1000 launches, host-paced) and as a hipGraph
@@ -836,6 +860,7 @@ def main():
         _log("roofline_hbm done")
         result["boundary_host_overhead"] = measure_boundary(model, inps[0])
         _log("boundary done")
+        result["host_handover"] = host_handover(device, dt / args.steps / clips_per_step * 1e3)
     if rank == 0 and world == 1 and not args.no_extras and bdec == 0:
         try:                                                         # an extra must never cost the headline
             result["rocm_eager_baseline"] = rocm_eager_baseline(model, inps[0])
