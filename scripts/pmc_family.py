@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per kernel family of a guided UNet forward (scripts/pmc_family.sh): share of time, matrix-pipe busy fraction
 (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), the normalisation of DESIGN.md 5.6 (4)), fraction of wave
-cycles spent waiting, and L1 -> L2 read requests (TCP_TCC_READ_REQ, 64 B each on gfx950: MI355X_MICROARCH.md) per second.
+cycles spent waiting, and L1 -> L2 read requests (TCP_TCC_READ_REQ, 128 B each: 67.1 M requests for the 8.6 GB of a 256x256 tiling of 8192^3) per second.
 usage: pmc_family.py pass_a.db pass_c.db"""
 import sqlite3
 import sys
@@ -42,10 +42,10 @@ def load(db):
 
 a, dur_a = load(sys.argv[1])
 cc, dur_c = load(sys.argv[2])
-tot = sum(dur_a.values())
+tot = sum(v for k, v in dur_a.items() if k != "other")
 print("# one pass = 2 eager guided (B = 2) UNet forwards under rocprofv3 --pmc; durations are those of the counter pass itself")
 print(f"{'family':44s} {'time %':>7s} {'MFMA busy':>10s} {'waiting':>8s} {'MFMA inst / VALU inst':>22s} {'L1->L2 read req TB/s':>21s} {'L2 hit':>7s}")
-for label in [l for _, l in FAMS] + ["other"]:
+for label in [l for _, l in FAMS]:                      # ("other" = the model-build kernels of the process)
     if label not in dur_a:
         continue
     x, y = a.get(label, {}), cc.get(label, {})
@@ -53,7 +53,7 @@ for label in [l for _, l in FAMS] + ["other"]:
     busy = x.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui / 8.0 * 1024.0) if gui else float("nan")
     wait = x.get("SQ_WAIT_ANY", 0.0) / x["SQ_WAVE_CYCLES"] if x.get("SQ_WAVE_CYCLES") else float("nan")
     ratio = x.get("SQ_INSTS_MFMA", 0.0) / x["SQ_INSTS_VALU"] if x.get("SQ_INSTS_VALU") else float("nan")
-    req = y.get("TCP_TCC_READ_REQ_sum", 0.0) * 64.0 / (dur_c.get(label, 0.0) * 1e-9) / 1e12 if dur_c.get(label) else float("nan")
+    req = y.get("TCP_TCC_READ_REQ_sum", 0.0) * 128.0 / (dur_c.get(label, 0.0) * 1e-9) / 1e12 if dur_c.get(label) else float("nan")
     hm = y.get("TCC_HIT_sum", 0.0) + y.get("TCC_MISS_sum", 0.0)
     hit = y.get("TCC_HIT_sum", 0.0) / hm if hm else float("nan")
     print(f"{label:44s} {100 * dur_a[label] / tot:7.1f} {busy:10.3f} {wait:8.3f} {ratio:22.3f} {req:21.2f} {hit:7.3f}")
