@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TC_ABI_VERSION 11
+#define TC_ABI_VERSION 12
 
 enum {
   TC_OK = 0,
@@ -237,6 +237,27 @@ int tc_groupnorm_part(const tc_bf16* x, tc_bf16* y, const float* gamma, const fl
 /* LayerNorm over the last axis of [rows, C] (attention.py:225-227), eps 1e-5, affine. */
 int tc_layernorm(const tc_bf16* x, tc_bf16* y, const float* gamma, const float* beta,
                  int32_t rows, int32_t c, float eps, void* stream);
+
+/* ABI 12 -- the same two norms, with a WEIGHT PREFETCH riding on the launch.  In the reference every norm is followed by the
+ * layer that consumes it (openaimodel3d.py:152-154,176-179,255-266: GroupNorm -> SiLU -> convolution; attention.py:242-246:
+ * LayerNorm -> attention / feed-forward projections), and inside a forward that layer's weights are always cold: 2.9 GB of
+ * parameters cycle through the 256 MB Infinity Cache once per forward.  For the 1280-channel levels of the UNet that costs
+ * the GEMM 7-29 % (profiles/r05_cold_operand_probe.txt); a read of the weights one launch ahead removes 93-100 % of it
+ * (profiles/r05_prefetch_premise_probe.txt).  `prefetch` names up to TC_PREFETCH_MAX read-only device buffers (ptr 16-byte
+ * aligned; whole 16-byte units of `bytes` are read, never a byte beyond); extra blocks of the norm's launch stream them
+ * through a load and drop the values -- y is bit-identical to tc_groupnorm / tc_layernorm, nothing else is written.
+ * prefetch == NULL or n == 0: exactly the plain entry point. */
+#define TC_PREFETCH_MAX 4
+typedef struct TcPrefetch {
+  const void* ptr[TC_PREFETCH_MAX];
+  int64_t bytes[TC_PREFETCH_MAX];
+  int32_t n;
+} TcPrefetch;
+int tc_groupnorm_pf(const tc_bf16* x, tc_bf16* y, const float* gamma, const float* beta,
+                    int32_t samples, int32_t rows, int32_t c, float eps, int32_t silu,
+                    void* workspace, int64_t workspace_bytes, const TcPrefetch* prefetch, void* stream);
+int tc_layernorm_pf(const tc_bf16* x, tc_bf16* y, const float* gamma, const float* beta,
+                    int32_t rows, int32_t c, float eps, const TcPrefetch* prefetch, void* stream);
 
 /* Row softmax fp32 [rows, n] -> bf16 [rows, ldo] for attention computed as GEMM + softmax + GEMM: the
  * single-head d=512 mid attention of the decoder (autoencoder_dualref.py:172-200) and the OpenCLIP towers

@@ -37,7 +37,7 @@ def main():
             body = asm[pos:end]
             if "s_endpgm" not in body:
                 continue
-            body = body[:body.index("s_endpgm")]
+            body = body[:body.rindex("s_endpgm")]           # the last exit (kernels with an early return have several)
             dem = subprocess.run(["c++filt", sym], capture_output=True, text=True).stdout.strip()
             dem = re.sub(r"\(anonymous namespace\)::", "", dem)
             dem = re.sub(r"\(.*$", "", dem).replace("void ", "")

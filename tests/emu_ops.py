@@ -193,7 +193,8 @@ class EmuOps:
         return self._out(o.permute(0, 3, 1, 2, 4).reshape(b * t * hw, c)).contiguous()
 
     # ------------------------------------------------------------------ norms
-    def groupnorm(self, x, gamma, beta, *, samples, rows, eps, silu=False, part=None):
+    def groupnorm(self, x, gamma, beta, *, samples, rows, eps, silu=False, part=None, prefetch=None):
+        # `prefetch` (ABI 12, the consumer's weights): a cache hint of the HIP path -- no arithmetic, nothing to emulate
         c = x.shape[1]
         if part is not None and part.of is x and rows % part.rows == 0 and part.sums.shape[2] == c \
                 and part.sums.shape[0] * part.rows == samples * rows:
@@ -216,11 +217,11 @@ class EmuOps:
             y = F.silu(y)
         return self._out(y.permute(0, 2, 1).reshape(samples * rows, c)).contiguous()
 
-    def gn_conv(self, x, gamma, beta, w, bias=None, *, samples, rows, eps, conv, silu=True, part=None, **kw):
+    def gn_conv(self, x, gamma, beta, w, bias=None, *, samples, rows, eps, conv, silu=True, part=None, prefetch_extra=(), **kw):
         h = self.groupnorm(x, gamma, beta, samples=samples, rows=rows, eps=eps, silu=silu, part=part)
         return self.gemm(h, w, bias, conv=conv, **kw)
 
-    def layernorm(self, x, gamma, beta, eps=1e-5, mx_for=None):
+    def layernorm(self, x, gamma, beta, eps=1e-5, mx_for=None, prefetch=None):
         return self._out(F.layer_norm(_f(x), (x.shape[1],), gamma, beta, eps))
 
     def softmax_rows(self, s, n=None, causal_period=0):

@@ -227,6 +227,67 @@ def test_guard_layernorm(hip, emu, rows, c):
     close(hip.layernorm(x, g, b), emu.layernorm(x, g, b), "guard layernorm")
 
 
+@pytest.mark.parametrize("samples,rows,c", [(1, 1, 64), (4, 4, 64), (2, 7, 320), (2, 160, 1280), (32, 40, 1280), (5, 3, 2560)])
+@pytest.mark.parametrize("pf_bytes", [(16,), (48, 4096), (1 << 20, 80, 65536 + 16, 3 << 20)])
+def test_guard_groupnorm_prefetch(hip, emu, samples, rows, c, pf_bytes):
+    """ABI 12: the prefetch planes read whole 16-byte units of every listed buffer and not a byte beyond (each buffer ends
+    flush with its own region); y is BIT-identical to the plain entry point -- one-launch and three-launch shapes."""
+    x = rnd(samples * rows, c, seed=25)
+    g, b = rnd(c, seed=26, dtype=torch.float32), rnd(c, seed=27, dtype=torch.float32)
+    pf = [rnd(n // 2, seed=40 + i) for i, n in enumerate(pf_bytes)]
+    hip.prefetch_min_bytes, keep = 0, hip.prefetch_min_bytes
+    try:
+        assert len(hip.prefetch_list(x.shape[0], pf)) == len(pf)
+        y = hip.groupnorm(x, g, b, samples=samples, rows=rows, eps=1e-5, silu=True, prefetch=pf)
+    finally:
+        hip.prefetch_min_bytes = keep
+    y0 = hip.groupnorm(x, g, b, samples=samples, rows=rows, eps=1e-5, silu=True)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y0)
+    close(y, emu.groupnorm(x, g, b, samples=samples, rows=rows, eps=1e-5, silu=True), "guard groupnorm + prefetch")
+
+
+@pytest.mark.parametrize("rows,c", [(1, 64), (3, 320), (17, 640), (2, 1280), (1280, 1280)])
+@pytest.mark.parametrize("pf_bytes", [(16,), (1 << 20, 80, 65536 + 16, 3 << 20)])
+def test_guard_layernorm_prefetch(hip, emu, rows, c, pf_bytes):
+    x = rnd(rows, c, seed=28)
+    g, b = rnd(c, seed=29, dtype=torch.float32), rnd(c, seed=30, dtype=torch.float32)
+    pf = [rnd(n // 2, seed=50 + i) for i, n in enumerate(pf_bytes)]
+    hip.prefetch_min_bytes, keep = 0, hip.prefetch_min_bytes
+    try:
+        y = hip.layernorm(x, g, b, prefetch=pf)
+    finally:
+        hip.prefetch_min_bytes = keep
+    y0 = hip.layernorm(x, g, b)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y0)
+    close(y, emu.layernorm(x, g, b), "guard layernorm + prefetch")
+
+
+def test_prefetch_argument_checks(hip):
+    """tc_*_pf: a misaligned or null buffer is an error code, an empty list is the plain call."""
+    import ctypes as C
+    from tooncrafter_amd import _lib
+    x = rnd(8, 64, seed=60)
+    g, b = rnd(64, seed=61, dtype=torch.float32), rnd(64, seed=62, dtype=torch.float32)
+    y = torch.empty_like(x)
+    w = rnd(4096, seed=63)
+    stream = torch.cuda.current_stream().cuda_stream
+    pf = _lib.TcPrefetch()
+    pf.n = 1
+    pf.ptr[0], pf.bytes[0] = w.data_ptr() + 2, 64
+    assert hip.lib.tc_layernorm_pf(x.data_ptr(), y.data_ptr(), g.data_ptr(), b.data_ptr(), 8, 64, 1e-5, C.byref(pf), stream) == -2
+    pf.ptr[0] = None
+    assert hip.lib.tc_layernorm_pf(x.data_ptr(), y.data_ptr(), g.data_ptr(), b.data_ptr(), 8, 64, 1e-5, C.byref(pf), stream) == -1
+    pf.n = 5
+    assert hip.lib.tc_layernorm_pf(x.data_ptr(), y.data_ptr(), g.data_ptr(), b.data_ptr(), 8, 64, 1e-5, C.byref(pf), stream) == -1
+    pf.n = 0
+    assert hip.lib.tc_layernorm_pf(x.data_ptr(), y.data_ptr(), g.data_ptr(), b.data_ptr(), 8, 64, 1e-5, C.byref(pf), stream) == 0
+    assert hip.lib.tc_layernorm_pf(x.data_ptr(), y.data_ptr(), g.data_ptr(), b.data_ptr(), 8, 64, 1e-5, None, stream) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y, hip.layernorm(x, g, b))
+
+
 def test_guard_softmax_layout_elementwise(hip, emu):
     s = rnd(5, 24, seed=31, dtype=torch.float32)
     close(hip.softmax_rows(s, n=21), emu.softmax_rows(s, n=21), "guard softmax")

@@ -52,6 +52,12 @@ def test_torch_ops_match_ctypes_binding_bitwise(both):
     assert torch.equal(t.groupnorm(xs, g, be, samples=4, rows=160, eps=1e-5, silu=True),
                        c.groupnorm(xs, g, be, samples=4, rows=160, eps=1e-5, silu=True))
     assert torch.equal(t.layernorm(xs, g, be), c.layernorm(xs, g, be))
+    # ABI 12: the consumer's weights as a prefetch list -- same policy, same result through both bindings
+    wpf = [rnd(1280, 2304, seed=40), rnd(640, 1280, seed=41)]
+    assert [x.data_ptr() for x in t.prefetch_list(xs.shape[0], wpf)] == [x.data_ptr() for x in wpf] and not t.prefetch_list(81920, wpf)
+    assert torch.equal(t.groupnorm(xs, g, be, samples=4, rows=160, eps=1e-5, silu=True, prefetch=wpf),
+                       c.groupnorm(xs, g, be, samples=4, rows=160, eps=1e-5, silu=True))
+    assert torch.equal(t.layernorm(xs, g, be, prefetch=wpf), c.layernorm(xs, g, be, prefetch=wpf))
     lat = [rnd(2, 4, 4, 8, 8, seed=s, dtype=torch.float32) for s in (16, 17, 18, 19)]
     sc = dict(cfg_scale=7.5, guidance_rescale=0.7, sqrt_ac=0.6, sqrt_1m_ac=0.8, sqrt_a_prev=0.7, dir_coef=0.5, sigma=0.3, x0_rescale=0.98)
     for u, v in zip(t.ddim_step(*lat, **sc), c.ddim_step(*lat, **sc)):

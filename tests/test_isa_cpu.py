@@ -51,7 +51,7 @@ def _kernels(asm):
         end = heads[i + 1][0] if i + 1 < len(heads) else len(asm)
         body = asm[pos:end]
         if "s_endpgm" in body:
-            out[name] = body[:body.index("s_endpgm")]
+            out[name] = body[:body.rindex("s_endpgm")]    # the LAST exit: a kernel may return early (ABI 12: prefetch planes)
     return out
 
 

@@ -16,7 +16,7 @@ def t():
 def test_operator_namespace_and_abi(t):
     assert int(t.abi_version()) == _lib.TC_ABI_VERSION
     for name in ("gemm", "quant_mxfp8", "gemm_mx", "attention", "attention_temporal", "groupnorm", "layernorm", "ddim_step",
-                 "ff_geglu_fused", "temporal_attn_fused"):
+                 "ff_geglu_fused", "temporal_attn_fused", "groupnorm_pf", "layernorm_pf"):
         op = getattr(t, name)
         schema = str(op.default._schema)
         assert schema.startswith(f"tooncrafter::{name}("), schema
@@ -46,6 +46,9 @@ def test_meta_kernels_infer_shapes(t):
     x = torch.empty(5120, 1280, **bf)
     g = torch.empty(1280, **f32)
     assert t.groupnorm(x, g, g, 32, 160, 1e-5, True).shape == x.shape and t.layernorm(x, g, g, 1e-5).dtype == torch.bfloat16
+    wpf = [torch.empty(1280, 11520, **bf), torch.empty(1280, 1280, **bf)]       # ABI 12: a consumer's weights ride on the norm
+    assert t.groupnorm_pf(x, g, g, 32, 160, 1e-5, True, wpf).shape == x.shape and t.layernorm_pf(x, g, g, 1e-5, wpf).shape == x.shape
+    assert "Tensor[] prefetch" in str(t.groupnorm_pf.default._schema)
     # the level-0 one-launch operators (ABI 9): rows in, rows out
     x0r = torch.empty(81920, 320, **bf)
     y = t.ff_geglu_fused(x0r, torch.empty(2560, 320, **bf), torch.empty(2560, **f32), torch.empty(320, 1280, **bf), torch.empty(320, **f32), 1e-5)

@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libtooncrafter_hip.so")
 
-TC_ABI_VERSION = 11
+TC_ABI_VERSION = 12
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_GEGLU = 0, 1, 2, 3
 GATHER_LINEAR, GATHER_CONV3x3, GATHER_CONVT3 = 0, 1, 2
 
@@ -86,6 +86,15 @@ class TcTbParams(C.Structure):
     ]
 
 
+TC_PREFETCH_MAX = 4
+
+
+class TcPrefetch(C.Structure):
+    """ABI 12: read-only device buffers (a consumer's weights) that extra blocks of a norm launch stream into the
+    Infinity Cache."""
+    _fields_ = [("ptr", C.c_void_p * TC_PREFETCH_MAX), ("bytes", C.c_int64 * TC_PREFETCH_MAX), ("n", C.c_int32)]
+
+
 SYMBOLS = {
     "tc_gemm_bf16": (C.c_int, [C.POINTER(TcGemmParams), C.c_void_p]),
     "tc_gemm_workspace": (C.c_int64, [C.POINTER(TcGemmParams)]),
@@ -102,6 +111,10 @@ SYMBOLS = {
                                C.c_float, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "tc_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float,
                                C.c_void_p]),
+    "tc_groupnorm_pf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_float, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(TcPrefetch), C.c_void_p]),
+    "tc_layernorm_pf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float,
+                                  C.POINTER(TcPrefetch), C.c_void_p]),
     "tc_softmax_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_void_p]),
     "tc_nchw_to_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,

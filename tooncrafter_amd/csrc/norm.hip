@@ -31,6 +31,47 @@ constexpr int GN_MAX_SLOTS = 2;       // 8-channel vectors per thread per row pa
 constexpr int GN_TARGET_BLOCKS = 512;     // 2 per CU: measured best of 128..8192 (profiles/r01_v6_norm_bench.txt)
 constexpr int GN_MIN_ROWS = 8;
 
+// ---- weight prefetch planes (ABI 12: tc_groupnorm_pf / tc_layernorm_pf) ------------------------------------------------
+// Inside the UNet forward every weight matrix is read once per forward -- 2.9 GB of weights cycle through a 256 MB Infinity
+// Cache, so a GEMM's W always comes from HBM, while a per-shape microbenchmark has it warm.  Measured
+// (profiles/r05_cold_operand_probe.txt): that costs the 1280-channel layers 7-29 % of their time (level 3: 16-29 %, level-2
+// 3x3 convolutions and projections ~10 %), nothing at levels 0 / 1 where W is small beside A -- and a read of W by ANOTHER
+// kernel one launch earlier takes 93-100 % of it away (profiles/r05_prefetch_premise_probe.txt).  The norm in front of a
+// GEMM is that other kernel: it is latency-bound at these sizes (10-15 us for 3-26 MB), so extra blocks that stream the
+// consumer's weights through a load and drop them ride in its shadow.  The extra blocks are whole grid PLANES (blockIdx.z >= 1
+// for GroupNorm, blockIdx.y >= 1 for LayerNorm): the norm's own blocks do not change.
+constexpr int PF_MAX = 4;
+struct PfArgs {
+  const u32x4* p[PF_MAX];
+  uint32_t units[PF_MAX];        // 16-byte units
+  int n;
+};
+
+// block b of nb prefetch blocks: its share of every tensor, 16 loads of 16 bytes per thread in flight, values dropped
+__device__ __forceinline__ void pf_run(const PfArgs& pf, uint32_t b, uint32_t nb, uint32_t tid, uint32_t nthr) {
+#pragma unroll 1
+  for (int i = 0; i < pf.n; ++i) {
+    const u32x4* src = pf.p[i];
+    const uint32_t units = pf.units[i];
+    uint32_t per = (units + nb - 1) / nb;
+    per = (per + 7u) & ~7u;                                   // whole 128-byte lines per block
+    const uint32_t lo = b * per;
+    if (lo >= units) continue;
+    const uint32_t hi = min(units, lo + per);
+#pragma unroll 1
+    for (uint32_t u = lo + tid; u < hi; u += nthr * 16u) {
+      u32x4 v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const uint32_t uu = u + (uint32_t)k * nthr;
+        v[k] = uu < hi ? src[uu] : u32x4{0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) asm volatile("" ::"v"(v[k][0]), "v"(v[k][1]), "v"(v[k][2]), "v"(v[k][3]));
+    }
+  }
+}
+
 struct GnGeo {
   int vpr;         // 8-channel vectors per row (C/8)
   int slots;       // vector slots per thread (1 or 2)
@@ -196,7 +237,12 @@ template <bool SILU>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               const float* __restrict__ stats, int rows, int c,
-                                                              int chunk_rows) {
+                                                              int chunk_rows, const PfArgs pf) {
+  if (blockIdx.z) {                                           // a weight-prefetch plane (ABI 12)
+    pf_run(pf, ((blockIdx.z - 1) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, (gridDim.z - 1) * gridDim.y * gridDim.x,
+           threadIdx.x, GN_THREADS);
+    return;
+  }
   const GnGeo g = gn_geo(c);
   const int tid = threadIdx.x;
   int rlane, vec[GN_MAX_SLOTS];
@@ -268,7 +314,12 @@ __device__ __forceinline__ void gn_opaque(u32x4& v) { asm volatile("" : "+v"(v[0
 template <int T, int NV, bool SILU>
 __global__ __launch_bounds__(T) void gn_onepass_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       int rows, int c, int vu, float eps) {
+                                                       int rows, int c, int vu, float eps, const PfArgs pf) {
+  if (blockIdx.z) {                                           // a weight-prefetch plane (ABI 12)
+    pf_run(pf, ((blockIdx.z - 1) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, (gridDim.z - 1) * gridDim.y * gridDim.x,
+           threadIdx.x, T);
+    return;
+  }
   constexpr int NW = T / 64;
   __shared__ float red[2][NW][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -390,7 +441,12 @@ template <int NV, int R, bool MX = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        int rows, int c, float eps, uint8_t* __restrict__ q = nullptr,
-                                                       int ldq = 0, uint8_t* __restrict__ sc = nullptr, int lds = 0) {
+                                                       int ldq = 0, uint8_t* __restrict__ sc = nullptr, int lds = 0,
+                                                       const PfArgs pf = PfArgs{}) {
+  if (blockIdx.y) {                                           // a weight-prefetch plane (ABI 12)
+    pf_run(pf, (blockIdx.y - 1) * gridDim.x + blockIdx.x, (gridDim.y - 1) * gridDim.x, threadIdx.x, 256);
+    return;
+  }
   const int lane = threadIdx.x & 63;
   const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
   if (row0 >= rows) return;
@@ -511,6 +567,33 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 
 }  // namespace
 
+// ABI 12: the caller's prefetch list -> kernel arguments.  Returns a TC_E* code; pf == nullptr or n == 0: nothing to prefetch.
+static int pf_args(const TcPrefetch* pf, PfArgs* out) {
+  PfArgs a{};
+  a.n = 0;
+  if (pf) {
+    if (pf->n < 0 || pf->n > TC_PREFETCH_MAX) return TC_EINVAL;
+    for (int i = 0; i < pf->n; ++i) {
+      if (!pf->ptr[i] || pf->bytes[i] < 0 || pf->bytes[i] > ((int64_t)1 << 35)) return TC_EINVAL;
+      if (!tc_aligned16(pf->ptr[i])) return TC_EALIGN;
+      const uint32_t units = (uint32_t)(pf->bytes[i] >> 4);      // whole 16-byte units only: never a byte beyond the tensor
+      if (!units) continue;
+      a.p[a.n] = reinterpret_cast<const u32x4*>(pf->ptr[i]);
+      a.units[a.n] = units;
+      ++a.n;
+    }
+  }
+  *out = a;
+  return TC_OK;
+}
+// planes of prefetch blocks beside a grid plane of `plane` blocks: at least ~512 blocks (one 16-deep pass of 256 threads
+// covers 64 KiB: 512 blocks = 32 MiB per pass), at most 8 planes
+static inline unsigned pf_planes(const PfArgs& a, int64_t plane) {
+  if (!a.n || plane <= 0) return 0;
+  const int64_t z = (512 + plane - 1) / plane;
+  return (unsigned)(z < 1 ? 1 : (z > 8 ? 8 : z));
+}
+
 // chunk height: ~GN_TARGET_BLOCKS blocks in flight, at least GN_MIN_ROWS rows each
 static inline void gn_chunking(int samples, int rows, int* nchunks, int* chunk_rows) {
   static const int target = [] { const char* e = getenv("TC_GN_BLOCKS"); const int v = e ? atoi(e) : 0;
@@ -533,10 +616,12 @@ extern "C" int64_t tc_groupnorm_workspace(int32_t samples, int32_t rows, int32_t
   return ((int64_t)samples * nch * 64 + (int64_t)samples * 64) * sizeof(float);
 }
 
-extern "C" int tc_groupnorm(const tc_bf16* x, tc_bf16* y, const float* gamma, const float* beta,
-                            int32_t samples, int32_t rows, int32_t c, float eps, int32_t silu,
-                            void* workspace, int64_t workspace_bytes, void* stream) {
+static int groupnorm_impl(const tc_bf16* x, tc_bf16* y, const float* gamma, const float* beta,
+                          int32_t samples, int32_t rows, int32_t c, float eps, int32_t silu,
+                          void* workspace, int64_t workspace_bytes, const TcPrefetch* prefetch, void* stream) {
   if (!x || !y || !gamma || !beta || !workspace || samples <= 0 || rows <= 0 || c <= 0) return TC_EINVAL;
+  PfArgs pf;
+  if (const int rc = pf_args(prefetch, &pf)) return rc;
   if ((c % 32) != 0 || c > GN_MAX_SLOTS * GN_THREADS * 8 || c > 4096) return TC_ESHAPE;
   if ((c % 8) != 0) return TC_ESHAPE;
   if (!tc_aligned16(x) || !tc_aligned16(y)) return TC_EALIGN;
@@ -552,7 +637,7 @@ extern "C" int tc_groupnorm(const tc_bf16* x, tc_bf16* y, const float* gamma, co
     const int vu = u / 8, gu = u / cpg;
     if (onepass && (c % u) == 0 && gu <= 4 && vu <= 64 && tc_aligned16(gamma) && tc_aligned16(beta)) {
       const int64_t nvec = (int64_t)rows * vu;
-      const dim3 grid(c / u, samples);
+      const dim3 grid(c / u, samples, 1 + pf_planes(pf, (int64_t)(c / u) * samples));
       const bf16_t* xb = reinterpret_cast<const bf16_t*>(x);
       bf16_t* yb = reinterpret_cast<bf16_t*>(y);
       auto fits = [&](int t, int nv) { return (int64_t)((rows + t / vu - 1) / (t / vu)) <= nv; };
@@ -564,11 +649,11 @@ extern "C" int tc_groupnorm(const tc_bf16* x, tc_bf16* y, const float* gamma, co
       bool done = nblk >= 128 || bytes <= (4 << 20);
       if (!done) {}
       else if (fits(256, 4)) {
-        if (silu) hipLaunchKernelGGL((gn_onepass_kernel<256, 4, true>), grid, dim3(256), 0, s, xb, yb, gamma, beta, rows, c, vu, eps);
-        else hipLaunchKernelGGL((gn_onepass_kernel<256, 4, false>), grid, dim3(256), 0, s, xb, yb, gamma, beta, rows, c, vu, eps);
+        if (silu) hipLaunchKernelGGL((gn_onepass_kernel<256, 4, true>), grid, dim3(256), 0, s, xb, yb, gamma, beta, rows, c, vu, eps, pf);
+        else hipLaunchKernelGGL((gn_onepass_kernel<256, 4, false>), grid, dim3(256), 0, s, xb, yb, gamma, beta, rows, c, vu, eps, pf);
       } else if (fits(256, 13)) {
-        if (silu) hipLaunchKernelGGL((gn_onepass_kernel<256, 13, true>), grid, dim3(256), 0, s, xb, yb, gamma, beta, rows, c, vu, eps);
-        else hipLaunchKernelGGL((gn_onepass_kernel<256, 13, false>), grid, dim3(256), 0, s, xb, yb, gamma, beta, rows, c, vu, eps);
+        if (silu) hipLaunchKernelGGL((gn_onepass_kernel<256, 13, true>), grid, dim3(256), 0, s, xb, yb, gamma, beta, rows, c, vu, eps, pf);
+        else hipLaunchKernelGGL((gn_onepass_kernel<256, 13, false>), grid, dim3(256), 0, s, xb, yb, gamma, beta, rows, c, vu, eps, pf);
       }
       else done = false;
       if (done) {
@@ -587,12 +672,26 @@ extern "C" int tc_groupnorm(const tc_bf16* x, tc_bf16* y, const float* gamma, co
   hipLaunchKernelGGL(gn_finalize_kernel, dim3((samples * 32 + 3) / 4), block, 0, s, part, stats, samples, rows, c, nch,
                      eps);
   TC_LAUNCH_CHECK();
-  if (silu) hipLaunchKernelGGL(gn_apply_kernel<true>, grid, block, 0, s, reinterpret_cast<const bf16_t*>(x),
-                               reinterpret_cast<bf16_t*>(y), gamma, beta, stats, rows, c, cr);
-  else hipLaunchKernelGGL(gn_apply_kernel<false>, grid, block, 0, s, reinterpret_cast<const bf16_t*>(x),
-                          reinterpret_cast<bf16_t*>(y), gamma, beta, stats, rows, c, cr);
+  // the weight-prefetch planes ride on the LAST of the three launches: the one right in front of the consumer
+  const dim3 agrid(nch, samples, 1 + pf_planes(pf, (int64_t)nch * samples));
+  if (silu) hipLaunchKernelGGL(gn_apply_kernel<true>, agrid, block, 0, s, reinterpret_cast<const bf16_t*>(x),
+                               reinterpret_cast<bf16_t*>(y), gamma, beta, stats, rows, c, cr, pf);
+  else hipLaunchKernelGGL(gn_apply_kernel<false>, agrid, block, 0, s, reinterpret_cast<const bf16_t*>(x),
+                          reinterpret_cast<bf16_t*>(y), gamma, beta, stats, rows, c, cr, pf);
   TC_LAUNCH_CHECK();
   return TC_OK;
+}
+
+extern "C" int tc_groupnorm(const tc_bf16* x, tc_bf16* y, const float* gamma, const float* beta,
+                            int32_t samples, int32_t rows, int32_t c, float eps, int32_t silu,
+                            void* workspace, int64_t workspace_bytes, void* stream) {
+  return groupnorm_impl(x, y, gamma, beta, samples, rows, c, eps, silu, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int tc_groupnorm_pf(const tc_bf16* x, tc_bf16* y, const float* gamma, const float* beta,
+                               int32_t samples, int32_t rows, int32_t c, float eps, int32_t silu,
+                               void* workspace, int64_t workspace_bytes, const TcPrefetch* prefetch, void* stream) {
+  return groupnorm_impl(x, y, gamma, beta, samples, rows, c, eps, silu, workspace, workspace_bytes, prefetch, stream);
 }
 
 extern "C" int tc_groupnorm_part(const tc_bf16* x, tc_bf16* y, const float* gamma, const float* beta, const float* part,
@@ -611,29 +710,44 @@ extern "C" int tc_groupnorm_part(const tc_bf16* x, tc_bf16* y, const float* gamm
                      part_rows, eps);
   TC_LAUNCH_CHECK();
   if (silu) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(nch, samples), dim3(GN_THREADS), 0, s, reinterpret_cast<const bf16_t*>(x),
-                               reinterpret_cast<bf16_t*>(y), gamma, beta, stats, rows, c, cr);
+                               reinterpret_cast<bf16_t*>(y), gamma, beta, stats, rows, c, cr, PfArgs{});
   else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(nch, samples), dim3(GN_THREADS), 0, s, reinterpret_cast<const bf16_t*>(x),
-                          reinterpret_cast<bf16_t*>(y), gamma, beta, stats, rows, c, cr);
+                          reinterpret_cast<bf16_t*>(y), gamma, beta, stats, rows, c, cr, PfArgs{});
+  TC_LAUNCH_CHECK();
+  return TC_OK;
+}
+
+static int layernorm_impl(const tc_bf16* x, tc_bf16* y, const float* gamma, const float* beta,
+                          int32_t rows, int32_t c, float eps, const TcPrefetch* prefetch, void* stream) {
+  if (!x || !y || !gamma || !beta || rows <= 0 || c <= 0) return TC_EINVAL;
+  if ((c % 8) != 0 || c > 4 * 64 * 8) return TC_ESHAPE;
+  if (!tc_aligned16(x) || !tc_aligned16(y) || !tc_aligned16(gamma) || !tc_aligned16(beta)) return TC_EALIGN;
+  PfArgs pf;
+  if (const int rc = pf_args(prefetch, &pf)) return rc;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const bf16_t* xb = reinterpret_cast<const bf16_t*>(x);
+  bf16_t* yb = reinterpret_cast<bf16_t*>(y);
+  const int rpb = c <= 512 ? 16 : (c <= 1024 ? 8 : 4);       // rows per block
+  const unsigned blocks = (unsigned)((rows + rpb - 1) / rpb);
+  const dim3 grid(blocks, 1 + pf_planes(pf, blocks));
+  if (c <= 512)
+    hipLaunchKernelGGL((layernorm_kernel<1, 4>), grid, dim3(256), 0, st, xb, yb, gamma, beta, rows, c, eps, nullptr, 0, nullptr, 0, pf);
+  else if (c <= 1024)
+    hipLaunchKernelGGL((layernorm_kernel<2, 2>), grid, dim3(256), 0, st, xb, yb, gamma, beta, rows, c, eps, nullptr, 0, nullptr, 0, pf);
+  else
+    hipLaunchKernelGGL((layernorm_kernel<4, 1>), grid, dim3(256), 0, st, xb, yb, gamma, beta, rows, c, eps, nullptr, 0, nullptr, 0, pf);
   TC_LAUNCH_CHECK();
   return TC_OK;
 }
 
 extern "C" int tc_layernorm(const tc_bf16* x, tc_bf16* y, const float* gamma, const float* beta,
                             int32_t rows, int32_t c, float eps, void* stream) {
-  if (!x || !y || !gamma || !beta || rows <= 0 || c <= 0) return TC_EINVAL;
-  if ((c % 8) != 0 || c > 4 * 64 * 8) return TC_ESHAPE;
-  if (!tc_aligned16(x) || !tc_aligned16(y) || !tc_aligned16(gamma) || !tc_aligned16(beta)) return TC_EALIGN;
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const bf16_t* xb = reinterpret_cast<const bf16_t*>(x);
-  bf16_t* yb = reinterpret_cast<bf16_t*>(y);
-  if (c <= 512)
-    hipLaunchKernelGGL((layernorm_kernel<1, 4>), dim3((rows + 15) / 16), dim3(256), 0, st, xb, yb, gamma, beta, rows, c, eps);
-  else if (c <= 1024)
-    hipLaunchKernelGGL((layernorm_kernel<2, 2>), dim3((rows + 7) / 8), dim3(256), 0, st, xb, yb, gamma, beta, rows, c, eps);
-  else
-    hipLaunchKernelGGL((layernorm_kernel<4, 1>), dim3((rows + 3) / 4), dim3(256), 0, st, xb, yb, gamma, beta, rows, c, eps);
-  TC_LAUNCH_CHECK();
-  return TC_OK;
+  return layernorm_impl(x, y, gamma, beta, rows, c, eps, nullptr, stream);
+}
+
+extern "C" int tc_layernorm_pf(const tc_bf16* x, tc_bf16* y, const float* gamma, const float* beta,
+                               int32_t rows, int32_t c, float eps, const TcPrefetch* prefetch, void* stream) {
+  return layernorm_impl(x, y, gamma, beta, rows, c, eps, prefetch, stream);
 }
 
 extern "C" int tc_layernorm_mxfp8(const tc_bf16* x, uint8_t* q, int32_t ldq, uint8_t* sc, int32_t lds, const float* gamma,

@@ -2,7 +2,7 @@
 //
 // The reference binds ATen / xformers operators from Python (utils/utils.py:27-42 instantiates lvdm classes whose
 // forward methods call torch ops); this registers the MI355X kernels as first-class torch operators instead:
-//   torch.ops.tooncrafter.gemm / quant_mxfp8 / gemm_mx / attention / attention_temporal / groupnorm / layernorm / ddim_step /
+//   torch.ops.tooncrafter.gemm / quant_mxfp8 / gemm_mx / attention / attention_temporal / groupnorm(_pf) / layernorm(_pf) / ddim_step /
 //   ff_geglu_fused / temporal_attn_fused
 // with (i) a CUDA(HIP)-key implementation that validates the tensors, allocates the result from the caching allocator,
 // picks up the CURRENT stream and calls the same extern "C" entry point the ctypes binding calls, and (ii) a Meta-key
@@ -227,6 +227,49 @@ Tensor groupnorm_cuda(const Tensor& x, const Tensor& gamma, const Tensor& beta, 
   return y;
 }
 
+// ABI 12: the consumer's weights (read-only CUDA tensors, contiguous) as a prefetch list for the norm's extra blocks
+TcPrefetch prefetch_of(at::TensorList ts, const char* what) {
+  TORCH_CHECK((int64_t)ts.size() <= TC_PREFETCH_MAX, what, ": at most ", TC_PREFETCH_MAX, " prefetch tensors");
+  TcPrefetch pf = {};
+  for (const Tensor& t : ts) {
+    TORCH_CHECK(t.is_cuda() && t.is_contiguous(), what, ": prefetch tensors must be contiguous CUDA tensors");
+    pf.ptr[pf.n] = t.data_ptr();
+    pf.bytes[pf.n] = (int64_t)t.numel() * (int64_t)t.element_size();
+    ++pf.n;
+  }
+  return pf;
+}
+
+Tensor groupnorm_pf_cuda(const Tensor& x, const Tensor& gamma, const Tensor& beta, int64_t samples, int64_t rows, double eps, bool silu,
+                         at::TensorList prefetch) {
+  check_rows(x, "groupnorm_pf: x");
+  const int64_t c = x.size(1);
+  TORCH_CHECK(x.is_contiguous() && x.size(0) == samples * rows, "groupnorm_pf: x must be contiguous [samples*rows, C]");
+  check_affine(gamma, beta, c, "groupnorm_pf");
+  const TcPrefetch pf = prefetch_of(prefetch, "groupnorm_pf");
+  Tensor y = at::empty_like(x);
+  const int64_t nbytes = tc_groupnorm_workspace((int32_t)samples, (int32_t)rows, (int32_t)c);
+  Tensor ws = at::empty({nbytes > 16 ? nbytes : 16}, x.options().dtype(at::kByte));
+  check_rc(tc_groupnorm_pf(bf(x), reinterpret_cast<tc_bf16*>(y.data_ptr()), gamma.data_ptr<float>(), beta.data_ptr<float>(),
+                           (int32_t)samples, (int32_t)rows, (int32_t)c, (float)eps, silu ? 1 : 0, ws.data_ptr(), nbytes, &pf, cur_stream()),
+           "tc_groupnorm_pf");
+  return y;
+}
+
+Tensor layernorm_pf_cuda(const Tensor& x, const Tensor& gamma, const Tensor& beta, double eps, at::TensorList prefetch) {
+  check_rows(x, "layernorm_pf: x");
+  TORCH_CHECK(x.is_contiguous(), "layernorm_pf: x must be contiguous");
+  check_affine(gamma, beta, x.size(1), "layernorm_pf");
+  const TcPrefetch pf = prefetch_of(prefetch, "layernorm_pf");
+  Tensor y = at::empty_like(x);
+  check_rc(tc_layernorm_pf(bf(x), reinterpret_cast<tc_bf16*>(y.data_ptr()), gamma.data_ptr<float>(), beta.data_ptr<float>(),
+                           (int32_t)x.size(0), (int32_t)x.size(1), (float)eps, &pf, cur_stream()), "tc_layernorm_pf");
+  return y;
+}
+
+Tensor groupnorm_pf_meta(const Tensor& x, const Tensor&, const Tensor&, int64_t, int64_t, double, bool, at::TensorList) { return at::empty_like(x); }
+Tensor layernorm_pf_meta(const Tensor& x, const Tensor&, const Tensor&, double, at::TensorList) { return at::empty_like(x); }
+
 // ---- the level-0 one-launch operators (ABI 9): LayerNorm + GEGLU feed-forward + residual; LayerNorm + temporal self-attention +
 // residual (lvdm/modules/attention.py:81-144,225-246,415-442).  ln_eps < 0: x is taken as already normalised.
 void check_w(const Tensor& t, at::ScalarType dt, const char* name) {
@@ -338,6 +381,8 @@ TORCH_LIBRARY(tooncrafter, m) {
   m.def("ff_geglu_fused(Tensor x, Tensor w1, Tensor b1, Tensor w2, Tensor b2, float ln_eps) -> Tensor");
   m.def("temporal_attn_fused(Tensor x, Tensor wqkv, Tensor bqkv, Tensor wo, Tensor bo, int b, int t, int hw, int heads, float ln_eps, float scale) -> Tensor");
   m.def("layernorm(Tensor x, Tensor gamma, Tensor beta, float eps) -> Tensor");
+  m.def("groupnorm_pf(Tensor x, Tensor gamma, Tensor beta, int samples, int rows, float eps, bool silu, Tensor[] prefetch) -> Tensor");
+  m.def("layernorm_pf(Tensor x, Tensor gamma, Tensor beta, float eps, Tensor[] prefetch) -> Tensor");
   m.def("ddim_step(Tensor x, Tensor e_cond, Tensor? e_uncond, Tensor? noise, Tensor? e_uncond_img, float cfg_scale, "
         "float cfg_img, float guidance_rescale, float sqrt_ac, float sqrt_1m_ac, float sqrt_a_prev, float dir_coef, "
         "float sigma, float x0_rescale) -> (Tensor, Tensor)");
@@ -352,6 +397,8 @@ TORCH_LIBRARY_IMPL(tooncrafter, CUDA, m) {
   m.impl("attention_temporal", attention_temporal_cuda);
   m.impl("groupnorm", groupnorm_cuda);
   m.impl("layernorm", layernorm_cuda);
+  m.impl("groupnorm_pf", groupnorm_pf_cuda);
+  m.impl("layernorm_pf", layernorm_pf_cuda);
   m.impl("ddim_step", ddim_step_cuda);
   m.impl("ff_geglu_fused", ff_geglu_fused_cuda);
   m.impl("temporal_attn_fused", temporal_attn_fused_cuda);
@@ -365,6 +412,8 @@ TORCH_LIBRARY_IMPL(tooncrafter, Meta, m) {
   m.impl("attention_temporal", attention_temporal_meta);
   m.impl("groupnorm", like_meta3);
   m.impl("layernorm", like_meta_ln);
+  m.impl("groupnorm_pf", groupnorm_pf_meta);
+  m.impl("layernorm_pf", layernorm_pf_meta);
   m.impl("ddim_step", ddim_step_meta);
   m.impl("ff_geglu_fused", ff_geglu_fused_meta);
   m.impl("temporal_attn_fused", temporal_attn_fused_meta);

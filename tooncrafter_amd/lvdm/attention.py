@@ -260,11 +260,12 @@ class BasicTransformerBlock(PackedModule):
         return {f"g{i}": f32(getattr(self, f"norm{i}").weight) for i in (1, 2, 3)} | \
                {f"b{i}": f32(getattr(self, f"norm{i}").bias) for i in (1, 2, 3)}
 
-    def _ln(self, x, i, consumer=None, gated=False):
+    def _ln(self, x, i, consumer=None, gated=False, prefetch=None):
         """`consumer`: the packed weight of the single linear GEMM that reads the normalised rows (fused qkv, GEGLU
-        projection) -- lets the fp8 route have LayerNorm emit MXFP8 directly; ignored otherwise."""
+        projection) -- lets the fp8 route have LayerNorm emit MXFP8 directly; ignored otherwise.  `prefetch`: packed
+        weights of the GEMMs behind this norm (ABI 12: the norm's launch streams them ahead where that pays)."""
         mx_for = None if consumer is None else (consumer.shape[0], consumer.shape[0] // 2 if gated else consumer.shape[0])
-        return ops.layernorm(x, self.pk[f"g{i}"], self.pk[f"b{i}"], self.LN_EPS, mx_for=mx_for)
+        return ops.layernorm(x, self.pk[f"g{i}"], self.pk[f"b{i}"], self.LN_EPS, mx_for=mx_for, prefetch=prefetch)
 
     def _folded(self, i, kind):
         """Consumer weights of norm<i> with the LayerNorm's affine half folded in (common.fold_layernorm), packed like
@@ -290,10 +291,12 @@ class BasicTransformerBlock(PackedModule):
             ent = cpk[key] = (stamp, folded)
         return (*ent[1], self.LN_EPS)
 
-    def _pre(self, x, i, consumer, kind):
+    def _pre(self, x, i, consumer, kind, then=None):
         """Input of the GEMM behind norm<i>: (LayerNorm(x), None), or -- when that GEMM can normalise its A rows itself
         (K = 320 at level 0: ops.gemm_ln_eligible, the library's own rule) -- (x, folded consumer weights): the
-        LayerNorm launch and its HBM round trip (reference attention.py:242-246 runs it as its own kernel) disappear."""
+        LayerNorm launch and its HBM round trip (reference attention.py:242-246 runs it as its own kernel) disappear.
+        `then`: the packed weight of the GEMM that follows the consumer (output projection, second feed-forward layer):
+        prefetched with the consumer's by the norm's launch (ABI 12)."""
         gated = kind == "ff"
         if gated:   # the one-launch feed-forward (csrc/ff_fused.hip) normalises its rows itself: raw rows + folded weights
             fused = getattr(ops.backend(), "ff_fused_eligible", None)
@@ -302,23 +305,23 @@ class BasicTransformerBlock(PackedModule):
         probe = getattr(ops.backend(), "gemm_ln_eligible", None)
         if probe is not None and probe(x.shape[0], consumer.shape[0], consumer.shape[1], geglu=gated, lda=x.stride(0)):
             return x, self._folded(i, kind)
-        return self._ln(x, i, consumer if kind != "q" else None, gated), None
+        return self._ln(x, i, consumer if kind != "q" else None, gated, prefetch=[consumer, then]), None
 
     def forward_spatial(self, x, act: Act, ctx: ContextCache, share: CfgShare = None):
         """`share` (first block of the UNet's first spatial transformer under batched guidance): x / act arrive at the
         single-copy batch; the guided passes part ways at the cross-attention, so the rows are repeated in front of it
         and (x, expanded act) is returned."""
         def self_attn(x=x):
-            h, ln = self._pre(x, 1, self.attn1.pk["wqkv"], "qkv")
+            h, ln = self._pre(x, 1, self.attn1.pk["wqkv"], "qkv", then=self.attn1.pk["wo"])
             return self.attn1.forward_spatial_self(h, x, act, ln=ln)
         x = self_attn() if share is None else share.cached(("attn1", id(self)), self_attn)
         if share is not None:
             if not share.branches:
                 x, act = ops.repeat_rows(x, share.n), share.expand(act)
             share.split(x)                                               # branches: every pass goes on alone, at batch b
-        h, ln = self._pre(x, 2, self.attn2.pk["wq"], "q")
+        h, ln = self._pre(x, 2, self.attn2.pk["wq"], "q", then=self.attn2.pk["wo"])
         x = self.attn2.forward_cross(h, x, act, ctx, ln=ln)
-        h, ln = self._pre(x, 3, self.ff.pk["w1"], "ff")
+        h, ln = self._pre(x, 3, self.ff.pk["w1"], "ff", then=self.ff.pk["w2"])
         out = self.ff(h, x, ln=ln)
         return out if share is None else (out, act)
 
@@ -331,13 +334,13 @@ class BasicTransformerBlock(PackedModule):
             w, bias, eps = self._folded(i, "qkv")
             return ops.temporal_attn_fused(x, w, bias, attn.pk["wo"], attn.pk["bo"], b=act.b, t=act.t, hw=act.hw,
                                            heads=attn.heads, ln_eps=eps, scale=attn.scale)
-        h, ln = self._pre(x, i, attn.pk["wqkv"], "qkv")
+        h, ln = self._pre(x, i, attn.pk["wqkv"], "qkv", then=attn.pk["wo"])
         return attn.forward_temporal_self(h, x, act, ln=ln)
 
     def forward_temporal(self, x, act: Act):
         x = self._temporal_attn(x, 1, self.attn1, act)
         x = self._temporal_attn(x, 2, self.attn2, act)                   # context=None -> self attention again
-        h, ln = self._pre(x, 3, self.ff.pk["w1"], "ff")
+        h, ln = self._pre(x, 3, self.ff.pk["w1"], "ff", then=self.ff.pk["w2"])
         return self.ff(h, x, ln=ln)
 
 
@@ -368,7 +371,7 @@ class SpatialTransformer(PackedModule):
         pk = self.pk
 
         def proj_in():
-            h = ops.groupnorm(act.rows, pk["gn_g"], pk["gn_b"], samples=act.frames, rows=act.hw, eps=1e-6)
+            h = ops.groupnorm(act.rows, pk["gn_g"], pk["gn_b"], samples=act.frames, rows=act.hw, eps=1e-6, prefetch=[pk["wi"]])
             return ops.gemm(h, pk["wi"], pk["bi"])
         h = proj_in() if share is None else share.cached(("proj_in", id(self)), proj_in)
         for blk in self.transformer_blocks:
@@ -402,7 +405,7 @@ class TemporalTransformer(PackedModule):
 
     def forward(self, act: Act) -> Act:
         pk = self.pk
-        h = ops.groupnorm(act.rows, pk["gn_g"], pk["gn_b"], samples=act.b, rows=act.t * act.hw, eps=1e-6)
+        h = ops.groupnorm(act.rows, pk["gn_g"], pk["gn_b"], samples=act.b, rows=act.t * act.hw, eps=1e-6, prefetch=[pk["wi"]])
         h = ops.gemm(h, pk["wi"], pk["bi"])
         for blk in self.transformer_blocks:
             h = blk.forward_temporal(h, act)

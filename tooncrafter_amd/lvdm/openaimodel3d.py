@@ -157,7 +157,7 @@ class ResBlock(TimestepBlock, PackedModule):
         gn = dict(samples=act.frames, rows=act.hw, eps=1e-5, silu=True)
         # both convolutions feed a GroupNorm (out_layers' / the temporal block's first): they emit its statistics (ABI 9)
         h, part = ops.gn_conv(act.rows, pk["g1"], pk["b1"], pk["w1"], pk["cb1"], conv=geom1, row_bias=emb_all[:, off:off + width],
-                              row_div=act.t * act.hw, gn_stats=True, **gn)
+                              row_div=act.t * act.hw, gn_stats=True, prefetch_extra=(pk["ws"],) if "ws" in pk else (), **gn)
         skip = act.rows if "ws" not in pk else ops.gemm(act.rows, pk["ws"], pk["bs"])
         geom2, _, _ = _conv_geom(act, self.out_channels)
         if not self.use_temporal_conv:

@@ -112,6 +112,14 @@ class HipOps:
         # 6.08 -> 5.72 on a slow lease) and the producing convolutions gain 0.4-1.1 ms (their epilogues fold 160 rows per
         # column and end on two block barriers): 7.79 vs 7.79 frames/s on one lease, 6.63 vs 6.75 on the other
         self.gn_part = os.environ.get("TC_GN_PART", "0") == "1"
+        # ABI 12: the norm in front of a GEMM streams that GEMM's weights into the Infinity Cache (tc_groupnorm_pf /
+        # tc_layernorm_pf).  Inside a forward W is always cold (2.9 GB of parameters per forward, 256 MB of cache); that
+        # costs the 1280-channel levels 7-29 % of their GEMM time and nothing where W is small beside A
+        # (profiles/r05_cold_operand_probe.txt, r05_prefetch_premise_probe.txt) -- hence the row bound.  TC_PREFETCH=0: never.
+        self.prefetch_on = os.environ.get("TC_PREFETCH", "1") != "0"
+        self.prefetch_max_rows = int(os.environ.get("TC_PREFETCH_MAX_ROWS", "8192"))
+        self.prefetch_min_bytes = 1 << 20
+        self.prefetch_max_bytes = 96 << 20
 
     # ------------------------------------------------------------------ workspace
     def _workspace(self, nbytes: int, device) -> torch.Tensor:
@@ -438,9 +446,37 @@ class HipOps:
         return out
 
     # ------------------------------------------------------------------ norms
-    def groupnorm(self, x, gamma, beta, *, samples, rows, eps, silu=False, part=None):
+    def prefetch_list(self, x_rows: int, tensors):
+        """Which of `tensors` (the packed weights of the GEMMs that consume a norm's output) the norm launch should
+        stream ahead of them: ONE rule for both bindings.  Only when the consumer is a small-M GEMM (its weights are then a
+        large share of its traffic), only tensors worth a request, at most TC_PREFETCH_MAX of them / 96 MB."""
+        if not self.prefetch_on or not tensors or x_rows > self.prefetch_max_rows:
+            return []
+        out, total = [], 0
+        for t in tensors:
+            if t is None or not isinstance(t, torch.Tensor) or not t.is_cuda or not t.is_contiguous():
+                continue
+            nbytes = t.numel() * t.element_size()
+            if nbytes < self.prefetch_min_bytes or total + nbytes > self.prefetch_max_bytes:
+                continue
+            out.append(t)
+            total += nbytes
+            if len(out) == _lib.TC_PREFETCH_MAX:
+                break
+        return out
+
+    @staticmethod
+    def _prefetch_struct(tensors):
+        pf = _lib.TcPrefetch()
+        for i, t in enumerate(tensors):
+            pf.ptr[i], pf.bytes[i] = t.data_ptr(), t.numel() * t.element_size()
+        pf.n = len(tensors)
+        return pf
+
+    def groupnorm(self, x, gamma, beta, *, samples, rows, eps, silu=False, part=None, prefetch=None):
         """x: contiguous [samples*rows, C]; statistics over (rows, C/32) per (sample, group).  `part` (a GnPart from
-        the gemm that produced x, or None): statistics from the producer's partial sums -- one pass over x, not two."""
+        the gemm that produced x, or None): statistics from the producer's partial sums -- one pass over x, not two.
+        `prefetch` (ABI 12): packed weights of the GEMMs that read the result (see prefetch_list)."""
         x = _rows_view(x)
         c = x.shape[1]
         if not x.is_contiguous() or x.shape[0] != samples * rows:
@@ -457,22 +493,32 @@ class HipOps:
                                                   rows, c, float(eps), 1 if silu else 0, ws.data_ptr(), nbytes, _stream()),
                        "tc_groupnorm_part")
             return y
+        pfl = self.prefetch_list(x.shape[0], prefetch)
+        if pfl:
+            pf = self._prefetch_struct(pfl)
+            _lib.check(self.lib.tc_groupnorm_pf(x.data_ptr(), y.data_ptr(), gp, bp, samples, rows, c, float(eps), 1 if silu else 0,
+                                                ws.data_ptr(), nbytes, C.byref(pf), _stream()), "tc_groupnorm_pf")
+            return y
         _lib.check(self.lib.tc_groupnorm(x.data_ptr(), y.data_ptr(), gp, bp, samples,
                                          rows, c, float(eps), 1 if silu else 0, ws.data_ptr(), nbytes, _stream()),
                    "tc_groupnorm")
         return y
 
-    def gn_conv(self, x, gamma, beta, w, bias=None, *, samples, rows, eps, conv, silu=True, part=None, **kw):
+    def gn_conv(self, x, gamma, beta, w, bias=None, *, samples, rows, eps, conv, silu=True, part=None, prefetch_extra=(), **kw):
         """conv(act(GroupNorm(x))) with the epilogue of `gemm` (**kw: row_bias / row_div / residual / act / gn_stats / out_f32):
         the reference's pair lvdm/basics.py:76-87 -> nn.Conv2d / nn.Conv3d (openaimodel3d.py:154,179,255-266) as ONE host
         operator, two launches.  (Round 5 measured the alternative -- the convolution normalising its own operand, ABI 10 --
         at -4 % per clip and removed it: DESIGN.md 5.6.)  `part`: see groupnorm."""
-        h = self.groupnorm(x, gamma, beta, samples=samples, rows=rows, eps=eps, silu=silu, part=part)
+        # ABI 12: the norm's launch brings the convolution's weights (and `prefetch_extra`: those of a GEMM right behind it,
+        # e.g. a ResBlock's 1x1 skip convolution) into the Infinity Cache where that pays (prefetch_list)
+        h = self.groupnorm(x, gamma, beta, samples=samples, rows=rows, eps=eps, silu=silu, part=part,
+                           prefetch=[w, *prefetch_extra])
         return self.gemm(h, w, bias, conv=conv, **kw)
 
-    def layernorm(self, x, gamma, beta, eps=1e-5, mx_for=None):
+    def layernorm(self, x, gamma, beta, eps=1e-5, mx_for=None, prefetch=None):
         """`mx_for` = (N, N_out) of the packed weight of the ONE linear GEMM that consumes the result: when the fp8
-        route takes that GEMM the row leaves as MXFP8 (an `MxRows`; the quantiser fused into its producer)."""
+        route takes that GEMM the row leaves as MXFP8 (an `MxRows`; the quantiser fused into its producer).
+        `prefetch` (ABI 12): packed weights of the GEMMs behind the norm (see prefetch_list)."""
         x = _rows_view(x)
         if not x.is_contiguous():
             raise ValueError("layernorm: x must be contiguous")
@@ -491,6 +537,12 @@ class HipOps:
                                                        float(eps), _stream()), "tc_layernorm_mxfp8")
                 return MxRows(q, sc, k)
         y = torch.empty_like(x)
+        pfl = self.prefetch_list(x.shape[0], prefetch)
+        if pfl:
+            pf = self._prefetch_struct(pfl)
+            _lib.check(self.lib.tc_layernorm_pf(x.data_ptr(), y.data_ptr(), gp, bp, x.shape[0], x.shape[1], float(eps),
+                                                C.byref(pf), _stream()), "tc_layernorm_pf")
+            return y
         _lib.check(self.lib.tc_layernorm(x.data_ptr(), y.data_ptr(), gp, bp,
                                          x.shape[0], x.shape[1], float(eps), _stream()), "tc_layernorm")
         return y

@@ -87,14 +87,20 @@ class TorchLibOps(HipOps):
         return self.t.temporal_attn_fused(x, wqkv, bqkv, wo, bo, int(b), int(t), int(hw), int(heads),
                                           -1.0 if ln_eps is None else float(ln_eps), float(64 ** -0.5 if scale is None else scale))
 
-    def groupnorm(self, x, gamma, beta, *, samples, rows, eps, silu=False, part=None):
+    def groupnorm(self, x, gamma, beta, *, samples, rows, eps, silu=False, part=None, prefetch=None):
         if part is not None:
-            return super().groupnorm(x, gamma, beta, samples=samples, rows=rows, eps=eps, silu=silu, part=part)
+            return super().groupnorm(x, gamma, beta, samples=samples, rows=rows, eps=eps, silu=silu, part=part, prefetch=prefetch)
+        pfl = self.prefetch_list(x.shape[0], prefetch)                      # ABI 12: the consumer's weights ride on the launch
+        if pfl:
+            return self.t.groupnorm_pf(x, gamma, beta, samples, rows, float(eps), bool(silu), pfl)
         return self.t.groupnorm(x, gamma, beta, samples, rows, float(eps), bool(silu))
 
-    def layernorm(self, x, gamma, beta, eps=1e-5, mx_for=None):
+    def layernorm(self, x, gamma, beta, eps=1e-5, mx_for=None, prefetch=None):
         if mx_for is not None and self.fp8 is not None:
-            return super().layernorm(x, gamma, beta, eps, mx_for=mx_for)
+            return super().layernorm(x, gamma, beta, eps, mx_for=mx_for, prefetch=prefetch)
+        pfl = self.prefetch_list(x.shape[0], prefetch)
+        if pfl:
+            return self.t.layernorm_pf(x, gamma, beta, float(eps), pfl)
         return self.t.layernorm(x, gamma, beta, float(eps))
 
     def ddim_step(self, x, e_cond, e_uncond, noise, *, cfg_scale, guidance_rescale, sqrt_ac, sqrt_1m_ac, sqrt_a_prev,
