@@ -221,7 +221,12 @@ class NormProbe:
             out = self.orig(x, *a, **kw)
             e1.record()
             self.rec.append((e0, e1, 4.0 * x.numel()))
+            # ABI 12: consumer weights this launch streams into the Infinity Cache beside its own work (ops.prefetch_list)
+            pfl = self.b.prefetch_list(x.shape[0] if x.dim() == 2 else x.numel() // x.shape[-1], kw.get("prefetch")) \
+                if hasattr(self.b, "prefetch_list") else []
+            self.pf.append(sum(t.numel() * t.element_size() for t in pfl))
             return out
+        self.pf = []
         self.b.groupnorm = groupnorm
         return self
 
@@ -260,6 +265,19 @@ def measure_roofline_hbm(model, inp):
         with NormProbe(ops.backend()) as probe:
             fwd()
         n, ms, by = probe.summary()
+        pf_launches, pf_bytes = sum(1 for b in probe.pf if b), float(sum(probe.pf))
+        # the same norms WITHOUT the weight-prefetch planes (ABI 12) riding on them: what the norm alone costs
+        hipb = ops.backend()
+        ms_plain = None
+        if getattr(hipb, "prefetch_on", False) and pf_launches:
+            hipb.prefetch_on = False
+            try:
+                fwd()
+                with NormProbe(hipb) as probe0:
+                    fwd()
+                _, ms_plain, _ = probe0.summary()
+            finally:
+                hipb.prefetch_on = True
         # the decoder's GroupNorms, separately: one eager 16-frame decode (60 norms over 128..512-channel activations)
         dec = model.first_stage_model.decoder
         z16 = torch.randn(1, 4, 16, 40, 64, device=x2.device)
@@ -284,6 +302,14 @@ def measure_roofline_hbm(model, inp):
                                                       "of a B=2 UNet forward; a committed counter run",
             "launches": n, "avg_launch_us": round(ms * 1e3 / max(n, 1), 2),
             "algorithmic_gb_per_unet_fwd_b2": round(by / 1e9, 3), "ms_per_unet_fwd_b2": round(ms, 3),
+            "weight_prefetch": None if ms_plain is None else {
+                "what": "ABI 12: extra blocks of the GroupNorm launches in front of the small-M GEMMs (UNet levels 2 / 3 / middle) "
+                        "stream those GEMMs' weights into the Infinity Cache; `achieved` / `frac` above count the norms' OWN "
+                        "algorithmic bytes over their duration WITH that stream riding along (the product path)",
+                "launches_carrying_it": pf_launches, "weight_gb_per_unet_fwd_b2": round(pf_bytes / 1e9, 3),
+                "ms_per_unet_fwd_b2_without": round(ms_plain, 3),
+                "frac_without": round(by / (ms_plain * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                "achieved_incl_weight_stream": round((by + pf_bytes) / (ms * 1e-3) / 1e9, 1)},
             "decoder_16f": {"launches": dn, "ms_per_decode": round(dms, 3), "algorithmic_gb_per_decode": round(dby / 1e9, 3),
                             "achieved": round(dgbs, 1), "frac": round(dgbs / PEAK_HBM_GBS, 4)}}
 
