@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 from conftest import ROOT
 
 
@@ -84,3 +86,25 @@ def test_fp8_routing_rule(monkeypatch):
     h = HipOps()
     assert not h._fp8_eligible(prm(20480, 1920, 640), False, 1920, 1)
     assert h._fp8_eligible(prm(81920, 320, 2880, GATHER_CONV3x3, 320), True, 320, 1)
+
+
+def test_prefetch_rule_is_one_host_function():
+    """ABI 12: which consumer weights a norm launch streams ahead is decided by ops.HipOps.prefetch_list alone (both
+    bindings call it): small-M consumers only, tensors worth a request, at most TC_PREFETCH_MAX / 96 MB per launch."""
+    import torch
+    from tooncrafter_amd import _lib
+    from tooncrafter_amd.ops import HipOps
+    h = HipOps()
+    big = [torch.empty(1280, 11520, dtype=torch.bfloat16), torch.empty(1280, 1280, dtype=torch.bfloat16)]      # 28 MB, 3.1 MB
+    small = torch.empty(320, 320, dtype=torch.bfloat16)                                                      # 0.2 MB
+    assert [t.data_ptr() for t in h.prefetch_list(5120, big)] == [t.data_ptr() for t in big]
+    assert h.prefetch_list(5120, [small, None, big[1]]) == [big[1]]                   # too small / absent: skipped
+    assert h.prefetch_list(20480, big) == [] and h.prefetch_list(81920, big) == []  # levels 0 / 1: W is small beside A
+    assert h.prefetch_list(5120, None) == [] and h.prefetch_list(5120, []) == []
+    assert len(h.prefetch_list(1280, [big[1]] * 7)) == _lib.TC_PREFETCH_MAX
+    assert h.prefetch_list(1280, [big[0]] * 4) == [big[0]] * 3                        # 96 MB per launch
+    assert h.prefetch_list(1280, [big[0].t()]) == []                                  # non-contiguous views are not streamed
+    h.prefetch_on = False
+    assert h.prefetch_list(5120, big) == []
+    with pytest.raises(_lib.TooncrafterHipError):
+        HipOps._prefetch_struct(big)                                                  # CPU tensors never cross the ABI

@@ -454,7 +454,7 @@ class HipOps:
             return []
         out, total = [], 0
         for t in tensors:
-            if t is None or not isinstance(t, torch.Tensor) or not t.is_cuda or not t.is_contiguous():
+            if t is None or not isinstance(t, torch.Tensor) or not t.is_contiguous():
                 continue
             nbytes = t.numel() * t.element_size()
             if nbytes < self.prefetch_min_bytes or total + nbytes > self.prefetch_max_bytes:
@@ -469,6 +469,8 @@ class HipOps:
     def _prefetch_struct(tensors):
         pf = _lib.TcPrefetch()
         for i, t in enumerate(tensors):
+            if not t.is_cuda:
+                raise _lib.TooncrafterHipError("prefetch: a CPU tensor in a norm's prefetch list: the product path is GPU-only")
             pf.ptr[i], pf.bytes[i] = t.data_ptr(), t.numel() * t.element_size()
         pf.n = len(tensors)
         return pf
