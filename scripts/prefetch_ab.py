@@ -54,20 +54,24 @@ with torch.no_grad():
     same = all(torch.equal(a, b) for a, b in zip((y_on if isinstance(y_on, (tuple, list)) else [y_on]),
                                                  (y_off if isinstance(y_off, (tuple, list)) else [y_off])))
     print(f"# outputs of the two forwards bit-identical: {same}")
-    # variants of the rule: (label, on, max rows of the consumer, smallest tensor worth a request)
-    variants = [("off", False, 8192, 1 << 20), ("on", True, 8192, 1 << 20)]
+    # variants of the rule: (label, on, max rows of the consumer, smallest tensor worth a request, plan)
+    variants = [("off", False, 8192, 1 << 20, 2), ("on", True, 8192, 1 << 20, 2)]
     if len(sys.argv) > 1 and sys.argv[1] == "sweep":
-        variants += [("on, rows <= 20480 (level 1 too)", True, 20480, 1 << 20), ("on, every level", True, 1 << 30, 1 << 20),
-                     ("on, tensors >= 256 KB", True, 8192, 256 << 10)]
-    graphs = {}
-    for name, flag, max_rows, min_bytes in variants:
-        hip.prefetch_on, hip.prefetch_max_rows, hip.prefetch_min_bytes = flag, max_rows, min_bytes
-        fwd()
+        variants += [("on, rows <= 20480 (level 1 too)", True, 20480, 1 << 20, 2), ("on, every level", True, 1 << 30, 1 << 20, 2),
+                     ("on, tensors >= 256 KB", True, 8192, 256 << 10, 2)]
+    if len(sys.argv) > 1 and sys.argv[1] == "plans":
+        variants += [("on, plan 1 (every norm its own consumer)", True, 8192, 1 << 20, 1)]
+    graphs, outs = {}, {}
+    for name, flag, max_rows, min_bytes, plan in variants:
+        hip.prefetch_on, hip.prefetch_max_rows, hip.prefetch_min_bytes, hip.prefetch_plan = flag, max_rows, min_bytes, plan
+        outs[name] = fwd()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             fwd()
         graphs[name] = g
+    print("# outputs bit-identical across the variants:", all(torch.equal(outs["off"], o) for o in outs.values()))
+    hip.prefetch_on, hip.prefetch_max_rows, hip.prefetch_min_bytes, hip.prefetch_plan = True, 8192, 1 << 20, 2
     N = 12
     rec = {k: [] for k in graphs}
     order = list(graphs)
