@@ -1,4 +1,5 @@
 #!/bin/bash
+# (measured and NOT shipped: plan 2 was -0.27 % where plan 1 was -0.10 %, on a slow-class lease -- profiles/r05_prefetch_plan2_ab_slow_lease.txt; the patch: scripts/experiments/prefetch_plan2.patch.txt)
 # Round 5, GPU visit 27: prefetch plan 2 (a level-3 ResBlock's per-frame norms carry the whole block's weights) against plan 1, then the model parity tests.
 cd "$(dirname "$0")/.."
 TAG=${1:-r5c27}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp

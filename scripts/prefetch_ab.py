@@ -59,7 +59,7 @@ with torch.no_grad():
     if len(sys.argv) > 1 and sys.argv[1] == "sweep":
         variants += [("on, rows <= 20480 (level 1 too)", True, 20480, 1 << 20, 2), ("on, every level", True, 1 << 30, 1 << 20, 2),
                      ("on, tensors >= 256 KB", True, 8192, 256 << 10, 2)]
-    if len(sys.argv) > 1 and sys.argv[1] == "plans":
+    if len(sys.argv) > 1 and sys.argv[1] == "plans":     # with scripts/experiments/prefetch_plan2.patch.txt applied (its plan 2 = the default there)
         variants += [("on, plan 1 (every norm its own consumer)", True, 8192, 1 << 20, 1)]
     graphs, outs = {}, {}
     for name, flag, max_rows, min_bytes, plan in variants:

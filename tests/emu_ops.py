@@ -217,8 +217,7 @@ class EmuOps:
             y = F.silu(y)
         return self._out(y.permute(0, 2, 1).reshape(samples * rows, c)).contiguous()
 
-    def gn_conv(self, x, gamma, beta, w, bias=None, *, samples, rows, eps, conv, silu=True, part=None, prefetch_extra=(),
-                prefetch_own=True, **kw):
+    def gn_conv(self, x, gamma, beta, w, bias=None, *, samples, rows, eps, conv, silu=True, part=None, prefetch_extra=(), **kw):
         h = self.groupnorm(x, gamma, beta, samples=samples, rows=rows, eps=eps, silu=silu, part=part)
         return self.gemm(h, w, bias, conv=conv, **kw)
 

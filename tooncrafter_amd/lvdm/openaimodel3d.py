@@ -98,17 +98,16 @@ class TemporalConvBlock(PackedModule):
             pk[f"w{i}"], pk[f"cb{i}"] = pack_convt3(seq[-1].weight), f32(seq[-1].bias)
         return pk
 
-    def forward(self, act: Act, part=None, own_prefetch=True) -> Act:
+    def forward(self, act: Act, part=None) -> Act:
         """`part`: GroupNorm partial sums of act.rows from the GEMM that produced them (ops.GnPart) or None.  Every
         convolution here feeds the next GroupNorm, so it is asked for the statistics of what it stores (ABI 9): the
-        norm then reads its input once instead of twice.  `own_prefetch` False: these norms do not stream their
-        convolutions' weights ahead (ABI 12; the enclosing ResBlock's norms did, or nobody does: ops.prefetch_plan)."""
+        norm then reads its input once instead of twice."""
         pk = self.pk
         y = act.rows
         geom = dict(kind="t3", frames=act.frames, t_len=act.t, cin=act.c, h_out=act.h, w_out=act.w)
         # GroupNorm + SiLU + convolution as ONE host operator (ops.gn_conv): two launches; round 5 measured the fused alternative -- a
         # statistics pass and a convolution that normalises its own operand
-        gn = dict(samples=act.b, rows=act.t * act.hw, eps=1e-5, silu=True, conv=geom, prefetch_own=own_prefetch)
+        gn = dict(samples=act.b, rows=act.t * act.hw, eps=1e-5, silu=True, conv=geom)
         for i in range(1, 5):
             if i < 4:
                 y, part = ops.gn_conv(y, pk[f"g{i}"], pk[f"b{i}"], pk[f"w{i}"], pk[f"cb{i}"], part=part, gn_stats=True, **gn)
@@ -157,25 +156,14 @@ class ResBlock(TimestepBlock, PackedModule):
         geom1, _, _ = _conv_geom(act, ceil_to(act.c, 64))
         gn = dict(samples=act.frames, rows=act.hw, eps=1e-5, silu=True)
         # both convolutions feed a GroupNorm (out_layers' / the temporal block's first): they emit its statistics (ABI 9)
-        # ABI 12, which norm streams which weights ahead of their GEMMs (ops.HipOps: prefetch_plan).  Plan 2, tiny activations
-        # (level 3 / middle): norm 1 carries both convolutions (+ the skip convolution), norm 2 the temporal block's four; the
-        # temporal block's own norms carry nothing at any level.  Plan 1: every norm its own consumer.
-        be = ops.backend()
-        plan2 = getattr(be, "prefetch_plan", 1) >= 2
-        whole = plan2 and act.frames * act.hw <= getattr(be, "prefetch_small_rows", 0)
-        extra1 = ((pk["ws"],) if "ws" in pk else ()) + ((pk["w2"],) if whole else ())
         h, part = ops.gn_conv(act.rows, pk["g1"], pk["b1"], pk["w1"], pk["cb1"], conv=geom1, row_bias=emb_all[:, off:off + width],
-                              row_div=act.t * act.hw, gn_stats=True, prefetch_extra=extra1, **gn)
+                              row_div=act.t * act.hw, gn_stats=True, prefetch_extra=(pk["ws"],) if "ws" in pk else (), **gn)
         skip = act.rows if "ws" not in pk else ops.gemm(act.rows, pk["ws"], pk["bs"])
         geom2, _, _ = _conv_geom(act, self.out_channels)
         if not self.use_temporal_conv:
-            return act.like(ops.gn_conv(h, pk["g2"], pk["b2"], pk["w2"], pk["cb2"], conv=geom2, part=part, residual=skip,
-                                        prefetch_own=not whole, **gn))
-        tpk = self.temopral_conv.pk
-        extra2 = tuple(tpk[f"w{i}"] for i in range(1, 5)) if whole else ()
-        h, part = ops.gn_conv(h, pk["g2"], pk["b2"], pk["w2"], pk["cb2"], conv=geom2, part=part, residual=skip, gn_stats=True,
-                              prefetch_own=not whole, prefetch_extra=extra2, **gn)
-        return self.temopral_conv(act.like(h), part, own_prefetch=not plan2)
+            return act.like(ops.gn_conv(h, pk["g2"], pk["b2"], pk["w2"], pk["cb2"], conv=geom2, part=part, residual=skip, **gn))
+        h, part = ops.gn_conv(h, pk["g2"], pk["b2"], pk["w2"], pk["cb2"], conv=geom2, part=part, residual=skip, gn_stats=True, **gn)
+        return self.temopral_conv(act.like(h), part)
 
 
 class TimestepEmbedSequential(nn.Sequential, TimestepBlock):

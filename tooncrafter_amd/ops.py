@@ -120,15 +120,6 @@ class HipOps:
         self.prefetch_max_rows = int(os.environ.get("TC_PREFETCH_MAX_ROWS", "8192"))
         self.prefetch_min_bytes = 1 << 20
         self.prefetch_max_bytes = 96 << 20
-        # Which norm carries which weights (lvdm/openaimodel3d.py).  Plan 2 (default): where the activations are tiny
-        # (<= prefetch_small_rows rows: level 3 / middle) a ResBlock's two per-frame GroupNorms carry the weights of the WHOLE
-        # block -- its convolutions and the four temporal convolutions behind them (nothing in between can evict 100 MB from a
-        # 256 MB cache) -- and the temporal block's own clip-wide norms carry nothing: those 64-block one-pass launches are a
-        # latency chain that a concurrent stream stretched by ~8 us each for ~6 us gained (profiles/
-        # r05_final_abi12_clip_kernel_stats_10step.txt); at level 2 the temporal convolutions (2 % to gain) are not streamed.
-        # Plan 1: every norm carries its own consumer's weights (the first version: profiles/r05_prefetch_forward_ab.txt).
-        self.prefetch_plan = int(os.environ.get("TC_PREFETCH_PLAN", "2"))
-        self.prefetch_small_rows = int(os.environ.get("TC_PREFETCH_SMALL_ROWS", "2048"))
 
     # ------------------------------------------------------------------ workspace
     def _workspace(self, nbytes: int, device) -> torch.Tensor:
@@ -515,8 +506,7 @@ class HipOps:
                    "tc_groupnorm")
         return y
 
-    def gn_conv(self, x, gamma, beta, w, bias=None, *, samples, rows, eps, conv, silu=True, part=None, prefetch_extra=(),
-                prefetch_own=True, **kw):
+    def gn_conv(self, x, gamma, beta, w, bias=None, *, samples, rows, eps, conv, silu=True, part=None, prefetch_extra=(), **kw):
         """conv(act(GroupNorm(x))) with the epilogue of `gemm` (**kw: row_bias / row_div / residual / act / gn_stats / out_f32):
         the reference's pair lvdm/basics.py:76-87 -> nn.Conv2d / nn.Conv3d (openaimodel3d.py:154,179,255-266) as ONE host
         operator, two launches.  (Round 5 measured the alternative -- the convolution normalising its own operand, ABI 10 --
@@ -524,7 +514,7 @@ class HipOps:
         # ABI 12: the norm's launch brings the convolution's weights (and `prefetch_extra`: those of a GEMM right behind it,
         # e.g. a ResBlock's 1x1 skip convolution) into the Infinity Cache where that pays (prefetch_list)
         h = self.groupnorm(x, gamma, beta, samples=samples, rows=rows, eps=eps, silu=silu, part=part,
-                           prefetch=[*([w] if prefetch_own else []), *prefetch_extra])
+                           prefetch=[w, *prefetch_extra])
         return self.gemm(h, w, bias, conv=conv, **kw)
 
     def layernorm(self, x, gamma, beta, eps=1e-5, mx_for=None, prefetch=None):
