@@ -104,6 +104,7 @@ def test_prefetch_rule_is_one_host_function():
     assert len(h.prefetch_list(1280, [big[1]] * 7)) == _lib.TC_PREFETCH_MAX
     assert h.prefetch_list(1280, [big[0]] * 4) == [big[0]] * 3                        # 96 MB per launch
     assert h.prefetch_list(1280, [big[0].t()]) == []                                  # non-contiguous views are not streamed
+    assert h.prefetch_list(1280, [big[0].view(-1)[1:1 + (1 << 20)]]) == []            # nor is a buffer that is not 16-byte aligned
     h.prefetch_on = False
     assert h.prefetch_list(5120, big) == []
     with pytest.raises(_lib.TooncrafterHipError):

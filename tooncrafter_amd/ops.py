@@ -454,8 +454,8 @@ class HipOps:
             return []
         out, total = [], 0
         for t in tensors:
-            if t is None or not isinstance(t, torch.Tensor) or not t.is_contiguous():
-                continue
+            if t is None or not isinstance(t, torch.Tensor) or not t.is_contiguous() or t.data_ptr() % 16:
+                continue                                              # (a hint: what the ABI would refuse is simply not streamed)
             nbytes = t.numel() * t.element_size()
             if nbytes < self.prefetch_min_bytes or total + nbytes > self.prefetch_max_bytes:
                 continue
