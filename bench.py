@@ -314,6 +314,14 @@ def measure_roofline_hbm(model, inp):
                             "achieved": round(dgbs, 1), "frac": round(dgbs / PEAK_HBM_GBS, 4)}}
 
 
+def _measured(fn, *a):
+    """A measurement taken beside the headline must never cost it: on an exception the field carries the error instead."""
+    try:
+        return fn(*a)
+    except Exception as e:                                           # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
 def _pmc_file(*names):
     pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     for name in names:
@@ -877,16 +885,16 @@ def main():
         _log("encoder done")
         result["frames_per_s_with_encoder"] = round(16.0 / (dt / args.steps / clips_per_step + enc_ms * 1e-3), 4)
     if rank == 0 and not args.no_roofline:
-        result["roofline"] = measure_roofline(model, inps[0])
-        if args.fp8:
+        result["roofline"] = _measured(measure_roofline, model, inps[0])
+        if args.fp8 and "error" not in result["roofline"]:
             result["roofline"]["note"] = ("--fp8: the timed launches include the routed tc_gemm_mxfp8 ones; FLOPs are priced "
                                           "against the bf16 peak all the same (dense MX fp8 peak: ~4.66 PF/s measured)")
         _log("roofline done")
-        result["roofline_hbm"] = measure_roofline_hbm(model, inps[0])
+        result["roofline_hbm"] = _measured(measure_roofline_hbm, model, inps[0])
         _log("roofline_hbm done")
-        result["boundary_host_overhead"] = measure_boundary(model, inps[0])
+        result["boundary_host_overhead"] = _measured(measure_boundary, model, inps[0])
         _log("boundary done")
-        result["host_handover"] = host_handover(device, dt / args.steps / clips_per_step * 1e3)
+        result["host_handover"] = _measured(host_handover, device, dt / args.steps / clips_per_step * 1e3)
     if rank == 0 and world == 1 and not args.no_extras and bdec == 0:
         try:                                                         # an extra must never cost the headline
             result["rocm_eager_baseline"] = rocm_eager_baseline(model, inps[0])
@@ -896,7 +904,7 @@ def main():
         result["binding_ab"] = other_binding_clip(args)
         _log("other binding clip done")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(model, inps[0])
+        result["cpu_baseline"] = _measured(cpu_baseline, model, inps[0])
     if rank == 0:
         print(json.dumps(result))
 
