@@ -6,8 +6,9 @@ kernels (lvdm/openclip.py).  The reference builds the networks with the third-pa
 this image lacks, so they are rebuilt here from the published ViT-H/14 hyper-parameters with open_clip's
 parameter names (towers pinned to HuggingFace transformers' CLIP: tests/test_openclip_golden_cpu.py).  Two host-side pieces of
 the reference live in third-party packages that are absent too; both are restated from their published algorithms -- the
-tokeniser pinned to transformers.CLIPTokenizer on a shared merge table, the resize with parity unpinned (no independent
-implementation of kornia's filter in this image):
+tokeniser pinned to transformers.CLIPTokenizer on a shared merge table, the resize pinned to a second, independent statement
+of kornia's algorithm on scipy.ndimage + a numpy Keys interpolation (tests/golden/make_resize_golden.py,
+tests/test_resize_pin_cpu.py: identical to 1e-12 in float64, 4e-5 as run in fp32):
   * tokenisation (`open_clip.tokenize`, open_clip_torch 2.22.0): `lvdm/clip_tokenizer.py`; the BPE merge table is DATA
     (open_clip's `bpe_simple_vocab_16e6.txt.gz`): with its path in `TC_CLIP_BPE_VOCAB` (or the package installed) any
     prompt is tokenised; without it, already-tokenised int64 (B, 77) tensors and the empty prompt "" (the scripts'
