@@ -850,6 +850,7 @@ def main():
             "output_finite": finite,
             "binding": ("torch.ops.tooncrafter (TORCH_LIBRARY custom ops over the C ABI)" if getattr(ops.backend(), "binding", "ctypes") == "torch"
                         else "ctypes over the C ABI"),
+            "binding_fallback": ops.binding_fallback(),        # None, or why the default custom-op layer was not taken
             **evidence,
         }
         mms = [c["matmul_8192_bf16_tflops"] for c in (calib_pre, calib_post) if c.get("matmul_8192_bf16_tflops")]

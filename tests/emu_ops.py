@@ -193,7 +193,7 @@ class EmuOps:
         return self._out(o.permute(0, 3, 1, 2, 4).reshape(b * t * hw, c)).contiguous()
 
     # ------------------------------------------------------------------ norms
-    def groupnorm(self, x, gamma, beta, *, samples, rows, eps, silu=False, part=None, prefetch=None):
+    def groupnorm(self, x, gamma, beta, *, samples, rows, eps, silu=False, part=None, prefetch=None, prefetch_linear=False):
         # `prefetch` (ABI 12, the consumer's weights): a cache hint of the HIP path -- no arithmetic, nothing to emulate
         c = x.shape[1]
         if part is not None and part.of is x and rows % part.rows == 0 and part.sums.shape[2] == c \

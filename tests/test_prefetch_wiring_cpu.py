@@ -77,3 +77,43 @@ def test_every_prefetched_tensor_is_the_weight_of_a_gemm_that_follows(tiny_sd, r
     # both kinds of norm take part, and some lists name two GEMMs (consumer + the one after it)
     assert any(k == "gn" for _, k, _ in offered) and any(k == "ln" for _, k, _ in offered)
     assert any(len(lst) >= 2 for _, _, lst in offered)
+
+
+def test_prefetch_list_leaves_out_what_the_fp8_route_reads_quantised():
+    """with the MXFP8 routing on, a consumer it takes reads a cached quantised copy of W, so the bf16 tensor is
+    not worth streaming.  The rule is HipOps.prefetch_list's alone (no GPU needed: it only looks at shapes)."""
+    be = ops.HipOps.__new__(ops.HipOps)
+    be.prefetch_on, be.prefetch_max_rows, be.prefetch_min_bytes, be.prefetch_max_bytes = True, 8192, 1 << 20, 96 << 20
+    be.fp8, be.fp8_min_m, be.fp8_min_k, be.fp8_min_n, be.fp8_n_over_k = None, 1024, 0, 0, 2.0
+    be.fp8_min_cin, be.fp8_max_cin = 0, 1280
+    wqkv = torch.empty(3840, 1280, dtype=torch.bfloat16)           # N >= 2 K: the fp8 route takes it
+    wo = torch.empty(1280, 1280, dtype=torch.bfloat16)             # narrow N: stays bf16
+    wg = torch.empty(10240, 1280, dtype=torch.bfloat16)            # GEGLU projection: taken
+    conv = torch.empty(1280, 11520, dtype=torch.bfloat16)          # a 3x3 convolution's packed weight
+    ids = lambda lst: [id(t) for t in lst]
+    assert ids(be.prefetch_list(5120, [wqkv, wo], linear=True)) == ids([wqkv, wo])
+    assert ids(be.prefetch_list(5120, [conv])) == ids([conv])
+    be.fp8 = "linear"
+    assert ids(be.prefetch_list(5120, [wqkv, wo], linear=True)) == ids([wo])
+    assert ids(be.prefetch_list(5120, [wg, wo], linear=True)) == ids([wo])
+    assert ids(be.prefetch_list(5120, [conv])) == ids([conv])       # "linear" routing leaves the convolutions in bf16
+    assert be.prefetch_list(512, [wqkv], linear=True) and True      # below fp8_min_m rows the route declines: streamed
+    be.fp8 = "all"
+    assert be.prefetch_list(5120, [conv]) == []                    # the convolutions read quantised weights too
+    assert ids(be.prefetch_list(5120, [wqkv, wo], linear=True)) == ids([wo])
+
+
+def test_stale_op_library_is_fatal_not_a_fallback(monkeypatch):
+    """an ABI mismatch of libtooncrafter_torch.so must not end in a silent ctypes run."""
+    from tooncrafter_amd import _lib, torch_ops
+    monkeypatch.setattr(ops, "_backend", None)
+    monkeypatch.setattr(torch_ops, "load", lambda: (_ for _ in ()).throw(_lib.TooncrafterAbiError("stale")))
+    monkeypatch.delenv("TC_BINDING", raising=False)
+    with pytest.raises(_lib.TooncrafterAbiError):
+        ops.backend()
+    # ... while a MISSING op library is a fallback that says so
+    monkeypatch.setattr(torch_ops, "load", lambda: (_ for _ in ()).throw(_lib.TooncrafterHipError("not found")))
+    monkeypatch.setattr(ops, "_binding_fallback", None)
+    be = ops.backend()
+    assert getattr(be, "binding", "ctypes") != "torch" and "not found" in ops.binding_fallback()
+    monkeypatch.setattr(ops, "_backend", None)

@@ -150,6 +150,10 @@ class TooncrafterHipError(RuntimeError):
     pass
 
 
+class TooncrafterAbiError(TooncrafterHipError):
+    """A library built against another ABI version was loaded: a stale build, never a reason to fall back."""
+
+
 def load():
     """dlopen the in-tree library and type every entry point.  Raises if absent."""
     global _lib

@@ -43,6 +43,7 @@
 
 #include "conv_halo_index.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace {
@@ -376,10 +377,20 @@ int tc_conv_halo_try(const TcGemmParams& p, int batch, hipStream_t s, bool dry) 
   if (p.gather != TC_GATHER_CONV3x3 && p.gather != TC_GATHER_CONVT3) return 0;
   if (mode == 1) {
     // a switch that selects among the IMPLICIT-GEMM kernels names the kernel under test / under measurement: keep out of its way
+    // (... and say so, once: an A/B script that exports one of them for ANOTHER reason also moves every 3x3 convolution to a
+    // different kernel, and a silent move is a confounded comparison -- ADVICE r5)
     for (const char* sw : {"TC_GEMM_TILE16", "TC_GEMM8", "TC_GEMM_PIPE", "TC_GEMM_SPLITK", "TC_GEMM_WS", "TC_G16_ILV", "TC_G16_TALL",
                            "TC_GEMM_WIDE", "TC_GEMM_ORDER", "TC_GEMM_NMAJOR"}) {
       const char* e = getenv(sw);
-      if (e && e[0]) return 0;
+      if (e && e[0]) {
+        static bool said = false;
+        if (!said && !dry) {
+          said = true;
+          fprintf(stderr, "[tooncrafter_hip] %s=%s is set: the 3x3 convolutions stay on the implicit-GEMM kernels "
+                          "(halo-patch route suppressed; TC_CONV_HALO=2 forces it)\n", sw, e);
+        }
+        return 0;
+      }
     }
     if (p.gather == TC_GATHER_CONV3x3) {
       const char* e = getenv("TC_CONV_HALO_3X3");

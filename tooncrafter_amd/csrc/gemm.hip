@@ -407,7 +407,9 @@ extern "C" int tc_gemm_gn_rows(const TcGemmParams* pp) {
   if (getenv("TC_GEMM_TILE") && getenv("TC_GEMM_TILE")[0]) return 0;          // forced tile families: tuning runs only
   if (const char* e = getenv("TC_GN_PART")) { if (e[0] == '0') return 0; }    // A/B switch: never emit
   if (tc_gemm_ws_try(p, batch, nullptr, true)) return 0;
-  if (tc_conv_halo_try(p, batch, nullptr, true) != 0) return 0;
+  // (no question to the halo-patch kernel: it emits no statistics, and tc_gemm_bf16 sets it aside for a call that carries
+  // gn_part -- so TC_GN_PART=1 measures what profiles/r04_gn_part_ab.txt measured, producer statistics from every
+  // 160 / 128-tile convolution, and not only from the few the halo route leaves over: ADVICE r5)
   if (tc_gemm8_try(p, batch, nullptr, true)) return 0;
   if (tc_gemm_tile16_try(p, batch, nullptr, true)) return 160;
   if (tc_gemm_wide_try(p, batch, nullptr, false, true)) return 0;
@@ -478,7 +480,7 @@ extern "C" int tc_gemm_bf16(const TcGemmParams* pp, void* stream) {
     return TC_OK;
   }
   if (p.a_norm) return TC_ESHAPE;                                      // only the weight-stationary kernel normalises A rows
-  if (force == 0 && !p.gn_part) {                                      // TC_CONV_HALO only (off by default): tap-reuse patches
+  if (force == 0 && !p.gn_part) {                                      // tap-reuse patches: the default route of the 3x3 convolutions of levels 0-2 (TC_CONV_HALO=0: never); a call that asks for producer statistics keeps the implicit GEMM, whose epilogue emits them
     const int r = tc_conv_halo_try(p, batch, s);
     if (r < 0) return TC_ESHAPE;                                       // strict mode (tests): a convolution it could not take
     if (r > 0) {

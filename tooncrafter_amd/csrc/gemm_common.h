@@ -282,4 +282,4 @@ int tc_gemm_wide_try(const TcGemmParams& p, int batch, hipStream_t s, bool force
 int tc_gemm_tile16_try(const TcGemmParams& p, int batch, hipStream_t s, bool dry = false);   // gemm16.hip; 1 = launched
 int tc_gemm_ws_try(const TcGemmParams& p, int batch, hipStream_t s, bool dry = false);       // gemm_ws.hip (K = 320); 1 = launched
 int tc_gemm8_try(const TcGemmParams& p, int batch, hipStream_t s, bool dry = false);         // gemm8.hip (8-wave 256x256 ping-pong); 1 = launched
-int tc_conv_halo_try(const TcGemmParams& p, int batch, hipStream_t s, bool dry = false);     // conv_halo.hip (tap-reuse patches; TC_CONV_HALO, off by default); 1 = launched, -1 = strict mode declined
+int tc_conv_halo_try(const TcGemmParams& p, int batch, hipStream_t s, bool dry = false);     // conv_halo.hip (tap-reuse patches; TC_CONV_HALO: 1 = the measured routing (default), 0 = never, 2 = strict); 1 = launched, -1 = strict mode declined

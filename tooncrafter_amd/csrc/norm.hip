@@ -587,11 +587,22 @@ static int pf_args(const TcPrefetch* pf, PfArgs* out) {
   return TC_OK;
 }
 // planes of prefetch blocks beside a grid plane of `plane` blocks: at least ~512 blocks (one 16-deep pass of 256 threads
-// covers 64 KiB: 512 blocks = 32 MiB per pass), at most 8 planes
+// covers 64 KiB: 512 blocks = 32 MiB per pass) in at most 8 planes -- unless the norm's own plane is so small (a one-pass
+// GroupNorm of a few (sample, unit) slabs, a LayerNorm over a few rows) that 8 planes would leave a handful of blocks
+// streaming megabytes each, serially, as the launch's critical path: then as many planes as give every 64 KiB
+// of the list its own block, up to 512 blocks / 64 planes.  The block count follows the BYTES, not the norm's size.
 static inline unsigned pf_planes(const PfArgs& a, int64_t plane) {
   if (!a.n || plane <= 0) return 0;
-  const int64_t z = (512 + plane - 1) / plane;
-  return (unsigned)(z < 1 ? 1 : (z > 8 ? 8 : z));
+  int64_t z = (512 + plane - 1) / plane;
+  if (z > 8) {
+    int64_t units = 0;
+    for (int i = 0; i < a.n; ++i) units += a.units[i];
+    int64_t need = (units * 16 + 65535) / 65536;             // blocks of one 16-deep pass
+    if (need > 512) need = 512;
+    const int64_t zn = (need + plane - 1) / plane;
+    z = zn > 8 ? (zn > 64 ? 64 : zn) : 8;
+  }
+  return (unsigned)(z < 1 ? 1 : z);
 }
 
 // chunk height: ~GN_TARGET_BLOCKS blocks in flight, at least GN_MIN_ROWS rows each

@@ -371,7 +371,7 @@ class SpatialTransformer(PackedModule):
         pk = self.pk
 
         def proj_in():
-            h = ops.groupnorm(act.rows, pk["gn_g"], pk["gn_b"], samples=act.frames, rows=act.hw, eps=1e-6, prefetch=[pk["wi"]])
+            h = ops.groupnorm(act.rows, pk["gn_g"], pk["gn_b"], samples=act.frames, rows=act.hw, eps=1e-6, prefetch=[pk["wi"]], prefetch_linear=True)
             return ops.gemm(h, pk["wi"], pk["bi"])
         h = proj_in() if share is None else share.cached(("proj_in", id(self)), proj_in)
         for blk in self.transformer_blocks:
@@ -405,7 +405,7 @@ class TemporalTransformer(PackedModule):
 
     def forward(self, act: Act) -> Act:
         pk = self.pk
-        h = ops.groupnorm(act.rows, pk["gn_g"], pk["gn_b"], samples=act.b, rows=act.t * act.hw, eps=1e-6, prefetch=[pk["wi"]])
+        h = ops.groupnorm(act.rows, pk["gn_g"], pk["gn_b"], samples=act.b, rows=act.t * act.hw, eps=1e-6, prefetch=[pk["wi"]], prefetch_linear=True)
         h = ops.gemm(h, pk["wi"], pk["bi"])
         for blk in self.transformer_blocks:
             h = blk.forward_temporal(h, act)

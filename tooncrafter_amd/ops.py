@@ -111,6 +111,9 @@ class HipOps:
         # r04_gn_part_ab.txt, same lease, alternating runs) GroupNorm loses 0.3-0.4 ms per guided forward (4.71 -> 4.39,
         # 6.08 -> 5.72 on a slow lease) and the producing convolutions gain 0.4-1.1 ms (their epilogues fold 160 rows per
         # column and end on two block barriers): 7.79 vs 7.79 frames/s on one lease, 6.63 vs 6.75 on the other
+        # (a call that carries gn_part keeps the implicit-GEMM kernels: the halo-patch route, the default for the 3x3
+        # convolutions of levels 0-2 since round 5, emits no statistics -- so TC_GN_PART=1 also moves those convolutions back,
+        # which is the routing the figures above were measured on)
         self.gn_part = os.environ.get("TC_GN_PART", "0") == "1"
         # ABI 12: the norm in front of a GEMM streams that GEMM's weights into the Infinity Cache (tc_groupnorm_pf /
         # tc_layernorm_pf).  Inside a forward W is always cold (2.9 GB of parameters per forward, 256 MB of cache); that
@@ -446,16 +449,27 @@ class HipOps:
         return out
 
     # ------------------------------------------------------------------ norms
-    def prefetch_list(self, x_rows: int, tensors):
+    def prefetch_list(self, x_rows: int, tensors, linear: bool = False):
         """Which of `tensors` (the packed weights of the GEMMs that consume a norm's output) the norm launch should
         stream ahead of them: ONE rule for both bindings.  Only when the consumer is a small-M GEMM (its weights are then a
-        large share of its traffic), only tensors worth a request, at most TC_PREFETCH_MAX of them / 96 MB."""
+        large share of its traffic), only tensors worth a request, at most TC_PREFETCH_MAX of them / 96 MB.
+        `linear`: the tensors are [N, K] weights of plain linear layers over these x_rows rows.  With the MXFP8 routing on
+        (opt-in, configs[4]) a consumer it takes reads a cached QUANTISED copy of W (`_weight_mx`), not this bf16 tensor:
+        streaming the bf16 one would be up to 96 MB of traffic and cache pollution for data nobody reads, so
+        those are left out -- per tensor for linear consumers, wholesale when the routing also takes convolutions."""
         if not self.prefetch_on or not tensors or x_rows > self.prefetch_max_rows:
+            return []
+        if self.fp8 is not None and not linear and self.fp8 != "linear":
             return []
         out, total = [], 0
         for t in tensors:
             if t is None or not isinstance(t, torch.Tensor) or not t.is_contiguous() or t.data_ptr() % 16:
                 continue                                              # (a hint: what the ABI would refuse is simply not streamed)
+            if self.fp8 is not None and linear and t.dim() == 2:
+                probe = TcGemmParams()
+                probe.m, probe.n, probe.k, probe.gather = x_rows, t.shape[0], t.shape[1], GATHER_LINEAR
+                if self._fp8_eligible(probe, False, t.shape[0], 1) or self._fp8_eligible(probe, False, t.shape[0] // 2, 1):
+                    continue                                          # (a GEGLU weight's N_out is N / 2: either answer means "taken")
             nbytes = t.numel() * t.element_size()
             if nbytes < self.prefetch_min_bytes or total + nbytes > self.prefetch_max_bytes:
                 continue
@@ -475,7 +489,7 @@ class HipOps:
         pf.n = len(tensors)
         return pf
 
-    def groupnorm(self, x, gamma, beta, *, samples, rows, eps, silu=False, part=None, prefetch=None):
+    def groupnorm(self, x, gamma, beta, *, samples, rows, eps, silu=False, part=None, prefetch=None, prefetch_linear=False):
         """x: contiguous [samples*rows, C]; statistics over (rows, C/32) per (sample, group).  `part` (a GnPart from
         the gemm that produced x, or None): statistics from the producer's partial sums -- one pass over x, not two.
         `prefetch` (ABI 12): packed weights of the GEMMs that read the result (see prefetch_list)."""
@@ -495,7 +509,7 @@ class HipOps:
                                                   rows, c, float(eps), 1 if silu else 0, ws.data_ptr(), nbytes, _stream()),
                        "tc_groupnorm_part")
             return y
-        pfl = self.prefetch_list(x.shape[0], prefetch)
+        pfl = self.prefetch_list(x.shape[0], prefetch, linear=prefetch_linear)
         if pfl:
             pf = self._prefetch_struct(pfl)
             _lib.check(self.lib.tc_groupnorm_pf(x.data_ptr(), y.data_ptr(), gp, bp, samples, rows, c, float(eps), 1 if silu else 0,
@@ -539,7 +553,7 @@ class HipOps:
                                                        float(eps), _stream()), "tc_layernorm_mxfp8")
                 return MxRows(q, sc, k)
         y = torch.empty_like(x)
-        pfl = self.prefetch_list(x.shape[0], prefetch)
+        pfl = self.prefetch_list(x.shape[0], prefetch, linear=True)
         if pfl:
             pf = self._prefetch_struct(pfl)
             _lib.check(self.lib.tc_layernorm_pf(x.data_ptr(), y.data_ptr(), gp, bp, x.shape[0], x.shape[1], float(eps),
@@ -681,6 +695,15 @@ class HipOps:
 _backend = None
 
 
+_binding_fallback = None
+
+
+def binding_fallback():
+    """None, or why the default custom-op binding was NOT taken and ctypes stepped in (bench.py prints it: a line that says
+    `binding: ctypes` by accident must be tellable from one that was asked for)."""
+    return _binding_fallback
+
+
 def backend():
     """The operator set behind `ops.gemm(...)` etc.  Two bindings over the ONE C ABI (include/tooncrafter_hip.h):
       TC_BINDING=torch (default since round 5): PyTorch-ROCm custom ops, `torch.ops.tooncrafter.*` (csrc/torch_ops.cpp,
@@ -700,10 +723,14 @@ def backend():
             from . import torch_ops
             try:
                 torch_ops.load()
+            except _lib.TooncrafterAbiError:                         # a STALE op library: fatal (its namespace is registered already)
+                raise
             except Exception as e:                                   # noqa: BLE001  (missing / unloadable op library)
                 if want == "torch":
                     raise
-                sys.stderr.write(f"[tooncrafter_amd] custom-op layer unavailable ({type(e).__name__}: {e}); using the ctypes binding\n")
+                global _binding_fallback
+                _binding_fallback = f"{type(e).__name__}: {e}"
+                sys.stderr.write(f"[tooncrafter_amd] custom-op layer unavailable ({_binding_fallback}); using the ctypes binding\n")
                 _backend = HipOps()
             else:
                 _backend = torch_ops.TorchLibOps()

@@ -29,8 +29,12 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise _lib.TooncrafterHipError(f"{LIB_PATH} not found: build it with `python -m tooncrafter_amd.build`")
     torch.ops.load_library(LIB_PATH)
-    if int(torch.ops.tooncrafter.abi_version()) != _lib.TC_ABI_VERSION:
-        raise _lib.TooncrafterHipError("libtooncrafter_torch.so was built against another ABI version")
+    got = int(torch.ops.tooncrafter.abi_version())
+    if got != _lib.TC_ABI_VERSION:
+        # fatal, not a reason to fall back to ctypes: the namespace is registered by now (TORCH_LIBRARY runs at dlopen), so
+        # `torch.ops.tooncrafter.*` would resolve to the stale layer for anybody who calls it directly
+        raise _lib.TooncrafterAbiError(f"{LIB_PATH} was built against ABI {got}, this tree is ABI {_lib.TC_ABI_VERSION}: "
+                                       "rebuild with `python -m tooncrafter_amd.build`")
     _loaded = True
     return torch.ops.tooncrafter
 
@@ -87,10 +91,11 @@ class TorchLibOps(HipOps):
         return self.t.temporal_attn_fused(x, wqkv, bqkv, wo, bo, int(b), int(t), int(hw), int(heads),
                                           -1.0 if ln_eps is None else float(ln_eps), float(64 ** -0.5 if scale is None else scale))
 
-    def groupnorm(self, x, gamma, beta, *, samples, rows, eps, silu=False, part=None, prefetch=None):
+    def groupnorm(self, x, gamma, beta, *, samples, rows, eps, silu=False, part=None, prefetch=None, prefetch_linear=False):
         if part is not None:
-            return super().groupnorm(x, gamma, beta, samples=samples, rows=rows, eps=eps, silu=silu, part=part, prefetch=prefetch)
-        pfl = self.prefetch_list(x.shape[0], prefetch)                      # ABI 12: the consumer's weights ride on the launch
+            return super().groupnorm(x, gamma, beta, samples=samples, rows=rows, eps=eps, silu=silu, part=part, prefetch=prefetch,
+                                     prefetch_linear=prefetch_linear)
+        pfl = self.prefetch_list(x.shape[0], prefetch, linear=prefetch_linear)   # ABI 12: the consumer's weights ride on the launch
         if pfl:
             return self.t.groupnorm_pf(x, gamma, beta, samples, rows, float(eps), bool(silu), pfl)
         return self.t.groupnorm(x, gamma, beta, samples, rows, float(eps), bool(silu))
@@ -98,7 +103,7 @@ class TorchLibOps(HipOps):
     def layernorm(self, x, gamma, beta, eps=1e-5, mx_for=None, prefetch=None):
         if mx_for is not None and self.fp8 is not None:
             return super().layernorm(x, gamma, beta, eps, mx_for=mx_for, prefetch=prefetch)
-        pfl = self.prefetch_list(x.shape[0], prefetch)
+        pfl = self.prefetch_list(x.shape[0], prefetch, linear=True)
         if pfl:
             return self.t.layernorm_pf(x, gamma, beta, float(eps), pfl)
         return self.t.layernorm(x, gamma, beta, float(eps))
