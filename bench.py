@@ -153,6 +153,7 @@ class GemmProbe:
         self.orig = backend.gemm
         self.orig_ff = getattr(backend, "ff_geglu_fused", None)
         self.orig_tb = getattr(backend, "temporal_attn_fused", None)
+        self.orig_tqa = getattr(backend, "temporal_qkv_attn", None)
         self.rec = []
 
     def __enter__(self):
@@ -176,6 +177,16 @@ class GemmProbe:
             self.rec.append((e0, e1, 2.0 * x.shape[0] * (wqkv.shape[0] * wqkv.shape[1] + wo.shape[0] * wo.shape[1])))
             return out
 
+        def tqa(x, wqkv, bqkv=None, **kw):
+            # the qkv projection + temporal attention launch of levels 1-3 (tc_temporal_qkv_attn, ABI 13): counted with the
+            # family at the FLOPs of the projection it contains and at its WHOLE duration (the attentions included)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = self.orig_tqa(x, wqkv, bqkv, **kw)
+            e1.record()
+            self.rec.append((e0, e1, 2.0 * x.shape[0] * wqkv.shape[0] * wqkv.shape[1]))
+            return out
+
         def gemm(a, w, bias=None, **kw):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -191,6 +202,8 @@ class GemmProbe:
             self.b.ff_geglu_fused = ff
         if self.orig_tb is not None:
             self.b.temporal_attn_fused = tb
+        if self.orig_tqa is not None:
+            self.b.temporal_qkv_attn = tqa
         return self
 
     def __exit__(self, *a):
@@ -199,6 +212,8 @@ class GemmProbe:
             self.b.ff_geglu_fused = self.orig_ff
         if self.orig_tb is not None:
             self.b.temporal_attn_fused = self.orig_tb
+        if self.orig_tqa is not None:
+            self.b.temporal_qkv_attn = self.orig_tqa
 
     def summary(self):
         torch.cuda.synchronize()
@@ -386,8 +401,8 @@ def measure_roofline(model, inp):
                        "a committed counter run, not measured in this process"
                        % (tj["traffic_bytes_per_forward"] / 1e9, tj.get("algorithmic_bytes_per_b2_forward", 43.2e9) / 1e9))
     return {"bound": "mfma", "kernel": "tc_gemm_bf16 family (gemm_kernel / gemm16 / gemm_wide / gemm_ws / gemm8: Linear and "
-                                       "implicit-GEMM convolutions, all gather modes; tc_ff_geglu_fused / tc_temporal_attn_fused counted as the "
-                                       "two products each fuses), UNet + decoder launches of one clip",
+                                       "implicit-GEMM convolutions, all gather modes; tc_ff_geglu_fused / tc_temporal_attn_fused / tc_temporal_qkv_attn counted at the "
+                                       "FLOPs of the projections each contains and at its whole duration), UNet + decoder launches of one clip",
             "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "launches": n, "avg_launch_us": round(ms * 1e3 / max(n, 1), 2),

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TC_ABI_VERSION 12
+#define TC_ABI_VERSION 13
 
 enum {
   TC_OK = 0,
@@ -180,6 +180,24 @@ typedef struct TcTbParams {
 } TcTbParams;
 int tc_temporal_attn_fused_eligible(const TcTbParams* p);
 int tc_temporal_attn_fused(const TcTbParams* p, void* stream);
+
+/* ABI 13 -- the fused q / k / v projection of a temporal self-attention and the attention itself as ONE launch
+ * (lvdm/modules/attention.py:81-144: to_q / to_k / to_v at :96-102, the per-head softmax(q k^T * scale) v over the T = 16
+ * frames of a pixel at :103-134 -- called with context = None from TemporalTransformer, attention.py:365-412):
+ *     out[:, h*64 .. h*64+63] = Attn_frames(x . wqkv[q_h | k_h | v_h]^T + bqkv),     every head h
+ * i.e. tc_gemm_bf16(x, wqkv) followed by tc_attn_temporal, without the [rows, 3c] tensor between them reaching HBM.
+ * `out` is what to_out (a tc_gemm_bf16 with bias and residual) takes next.  t = 16, c = heads * 64, hw % 8 == 0
+ * (tc_temporal_qkv_attn_eligible); UNet levels 1-3 (c = 640 / 1280) -- level 0 has tc_temporal_attn_fused.
+ *   x     [b*t*hw, ldx] bf16, row = (batch * t + frame) * hw + pixel: the projection's input (the LayerNorm's output);
+ *   wqkv  [3*c, c] bf16: rows [0, c) = to_q, [c, 2c) = to_k, [2c, 3c) = to_v (head h at h*64) -- tc_gemm_bf16's operand;
+ *   bqkv  [3*c] fp32 or NULL (the reference's projections have no bias);   out [b*t*hw, ldo] bf16;   scale = 64^-0.5. */
+typedef struct TcTqaParams {
+  const tc_bf16* x; const tc_bf16* wqkv; const float* bqkv; tc_bf16* out;
+  int32_t b, t, hw, c, heads, ldx, ldo;
+  float scale;
+} TcTqaParams;
+int tc_temporal_qkv_attn_eligible(const TcTqaParams* p);
+int tc_temporal_qkv_attn(const TcTqaParams* p, void* stream);
 
 typedef struct TcAttnParams {
   const tc_bf16* q; const tc_bf16* k; const tc_bf16* v; tc_bf16* o;

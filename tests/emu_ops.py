@@ -22,12 +22,14 @@ def _f(t):
 class EmuOps:
     name = "emu"
 
-    def __init__(self, round_bf16=True, ln_fusion_k=None, gn_rows=0, ff_fused_c=None, tb_fused_c=None):
+    def __init__(self, round_bf16=True, ln_fusion_k=None, gn_rows=0, ff_fused_c=None, tb_fused_c=None, tqa=False):
         self.round = round_bf16
         self.ff_fused_c = ff_fused_c         # tests only: width whose feed-forward takes the one-launch route (the library: 320)
         self.ff_fused_calls = 0
         self.tb_fused_c = tb_fused_c         # tests only: width whose temporal self-attention takes the one-launch route (library: 320)
         self.tb_fused_calls = 0
+        self.tqa = tqa                       # tests only: offer the qkv + attention launch (ABI 13; library: wherever c = heads * 64, t = 16, hw % 8 == 0)
+        self.tqa_calls = 0
         self.ln_fusion_k = ln_fusion_k       # tests only: accept a_norm_eps for EVERY consumer with this K.  The HIP library's
                                              # default rule (csrc/gemm_ws.hip: ws_shape_ok, mode 1) is narrower: K = 320, N = 320,
                                              # no GEGLU, M >= 65536 -- only the level-0 projections; TC_GEMM_WS=2 widens it to the
@@ -59,6 +61,15 @@ class EmuOps:
         qkv = self.gemm(x, wqkv, bqkv, a_norm_eps=ln_eps) if ln_eps is not None else self.gemm(x, wqkv, bqkv)
         a = self.attention_temporal(qkv, b=b, t=t, hw=hw, heads=heads, scale=scale)
         return self.gemm(a, wo, bo, residual=x)
+
+    def temporal_qkv_attn_eligible(self, *, b, t, hw, c, heads, ldx=None):
+        return bool(self.tqa) and t == 16 and heads * 64 == c and hw % 8 == 0
+
+    def temporal_qkv_attn(self, x, wqkv, bqkv=None, *, b, t, hw, heads, scale=None):
+        """csrc/qkv_attn.hip: the roundings of the two launches it replaces (q / k / v and the attention output in bf16, fp32
+        sums; its softmax weights are bf16 where tc_attn_temporal keeps fp32 -- inside the operator bound)."""
+        self.tqa_calls += 1
+        return self.attention_temporal(self.gemm(x, wqkv, bqkv), b=b, t=t, hw=hw, heads=heads, scale=scale)
 
     def _out(self, x, f32=False):
         if f32:

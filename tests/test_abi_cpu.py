@@ -33,7 +33,7 @@ def test_struct_layout_matches_header():
         header = f.read()
     for cname, ctype in (("TcGemmParams", _lib.TcGemmParams), ("TcAttnParams", _lib.TcAttnParams),
                          ("TcDdimParams", _lib.TcDdimParams), ("TcGemmMxParams", _lib.TcGemmMxParams),
-                         ("TcFfParams", _lib.TcFfParams), ("TcTbParams", _lib.TcTbParams)):
+                         ("TcFfParams", _lib.TcFfParams), ("TcTbParams", _lib.TcTbParams), ("TcTqaParams", _lib.TcTqaParams)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), header, re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []

@@ -86,3 +86,26 @@ def test_temporal_attention_takes_the_fused_operator_when_offered():
     rel = float((outs[320] - outs[None]).norm() / outs[None].norm())
     print("fused temporal attention on/off (emulation):", rel)
     assert rel < 1e-2 and torch.equal(outs[640], outs[None])
+
+
+def test_temporal_attention_takes_the_qkv_attention_launch_when_offered():
+    """Where the level-0 fusion does not apply, CrossAttention.forward_temporal_self hands the projection AND the attentions
+    to temporal_qkv_attn (ABI 13, csrc/qkv_attn.hip) when the backend offers it -- the same arithmetic as gemm +
+    attention_temporal, so on the emulation the block's output is the same bits; a backend that also offers the level-0
+    fusion for the width keeps that one (it swallows more)."""
+    from test_ln_fusion_cpu import _make_block
+    temporal = _make_block(None)
+    outs, calls = {}, {}
+    for key, kw in (("off", {}), ("tqa", dict(tqa=True)), ("both", dict(tqa=True, tb_fused_c=320))):
+        emu = EmuOps(round_bf16=True, **kw)
+        prev = ops.set_backend(emu)
+        try:
+            b, t, h, w = 1, 16, 2, 4
+            x = torch.randn(b * t * h * w, 320, generator=torch.Generator().manual_seed(5)).to(torch.bfloat16)
+            with torch.no_grad():
+                outs[key] = temporal.forward_temporal(x, Act(x, b, t, h, w)).float()
+        finally:
+            ops.set_backend(prev)
+        calls[key] = (emu.tqa_calls, emu.tb_fused_calls)
+    assert calls == {"off": (0, 0), "tqa": (2, 0), "both": (0, 2)}, calls
+    assert torch.equal(outs["tqa"], outs["off"])

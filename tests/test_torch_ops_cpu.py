@@ -16,7 +16,7 @@ def t():
 def test_operator_namespace_and_abi(t):
     assert int(t.abi_version()) == _lib.TC_ABI_VERSION
     for name in ("gemm", "quant_mxfp8", "gemm_mx", "attention", "attention_temporal", "groupnorm", "layernorm", "ddim_step",
-                 "ff_geglu_fused", "temporal_attn_fused", "groupnorm_pf", "layernorm_pf"):
+                 "ff_geglu_fused", "temporal_attn_fused", "temporal_qkv_attn", "groupnorm_pf", "layernorm_pf"):
         op = getattr(t, name)
         schema = str(op.default._schema)
         assert schema.startswith(f"tooncrafter::{name}("), schema
@@ -56,6 +56,12 @@ def test_meta_kernels_infer_shapes(t):
     y = t.temporal_attn_fused(x0r, torch.empty(960, 320, **bf), torch.empty(960, **f32), torch.empty(320, 320, **bf), torch.empty(320, **f32),
                               2, 16, 2560, 5, 1e-5, 0.125)
     assert y.shape == (81920, 320)
+    # ABI 13: qkv projection + temporal attention as one launch (levels 1-3): rows in, rows out, the bias optional
+    x1r = torch.empty(20480, 640, **bf)
+    y = t.temporal_qkv_attn(x1r, torch.empty(1920, 640, **bf), None, 2, 16, 640, 10, 0.125)
+    assert y.shape == (20480, 640) and y.dtype == torch.bfloat16
+    assert t.temporal_qkv_attn(x1r, torch.empty(1920, 640, **bf), torch.empty(1920, **f32), 2, 16, 640, 10, 0.125).shape == (20480, 640)
+    assert "Tensor? bqkv" in str(t.temporal_qkv_attn.default._schema)
     lat = torch.empty(1, 4, 16, 40, 64, **f32)
     xp, x0 = t.ddim_step(lat, lat, lat, lat, None, 7.5, 7.5, 0.7, 0.6, 0.8, 0.7, 0.5, 0.3, 0.98)
     assert xp.shape == lat.shape and x0.shape == lat.shape

@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libtooncrafter_hip.so")
 
-TC_ABI_VERSION = 12
+TC_ABI_VERSION = 13
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_GEGLU = 0, 1, 2, 3
 GATHER_LINEAR, GATHER_CONV3x3, GATHER_CONVT3 = 0, 1, 2
 
@@ -86,6 +86,16 @@ class TcTbParams(C.Structure):
     ]
 
 
+class TcTqaParams(C.Structure):
+    """ABI 13: temporal qkv projection + attention as one launch (csrc/qkv_attn.hip)."""
+    _fields_ = [
+        ("x", C.c_void_p), ("wqkv", C.c_void_p), ("bqkv", C.c_void_p), ("out", C.c_void_p),
+        ("b", C.c_int32), ("t", C.c_int32), ("hw", C.c_int32), ("c", C.c_int32), ("heads", C.c_int32),
+        ("ldx", C.c_int32), ("ldo", C.c_int32),
+        ("scale", C.c_float),
+    ]
+
+
 TC_PREFETCH_MAX = 4
 
 
@@ -139,6 +149,8 @@ SYMBOLS = {
     "tc_ff_geglu_fused": (C.c_int, [C.POINTER(TcFfParams), C.c_void_p]),
     "tc_temporal_attn_fused_eligible": (C.c_int, [C.POINTER(TcTbParams)]),
     "tc_temporal_attn_fused": (C.c_int, [C.POINTER(TcTbParams), C.c_void_p]),
+    "tc_temporal_qkv_attn_eligible": (C.c_int, [C.POINTER(TcTqaParams)]),
+    "tc_temporal_qkv_attn": (C.c_int, [C.POINTER(TcTqaParams), C.c_void_p]),
     "tc_abi_version": (C.c_int, []),
     "tc_build_info": (C.c_char_p, []),
 }

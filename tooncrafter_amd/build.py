@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtooncrafter_hip.so")
-SOURCES = ["gemm.hip", "gemm_wide.hip", "gemm16.hip", "conv_halo.hip", "gemm8.hip", "ff_fused.hip", "tb_fused.hip", "gemm_ws.hip", "gemm_mx.hip", "attention.hip", "norm.hip", "elementwise.hip"]
+SOURCES = ["gemm.hip", "gemm_wide.hip", "gemm16.hip", "conv_halo.hip", "gemm8.hip", "ff_fused.hip", "tb_fused.hip", "qkv_attn.hip", "gemm_ws.hip", "gemm_mx.hip", "attention.hip", "norm.hip", "elementwise.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "gemm_epilogue.h"), os.path.join(CSRC, "gemm_persist.h"), os.path.join(CSRC, "conv_halo_index.h"),
            os.path.join(ROOT, "include", "tooncrafter_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on",

@@ -3,7 +3,7 @@
 // The reference binds ATen / xformers operators from Python (utils/utils.py:27-42 instantiates lvdm classes whose
 // forward methods call torch ops); this registers the MI355X kernels as first-class torch operators instead:
 //   torch.ops.tooncrafter.gemm / quant_mxfp8 / gemm_mx / attention / attention_temporal / groupnorm(_pf) / layernorm(_pf) / ddim_step /
-//   ff_geglu_fused / temporal_attn_fused
+//   ff_geglu_fused / temporal_attn_fused / temporal_qkv_attn
 // with (i) a CUDA(HIP)-key implementation that validates the tensors, allocates the result from the caching allocator,
 // picks up the CURRENT stream and calls the same extern "C" entry point the ctypes binding calls, and (ii) a Meta-key
 // implementation (shape / dtype inference only) so the ops can be traced, exported and shape-checked without a GPU.
@@ -324,6 +324,31 @@ Tensor temporal_attn_fused_meta(const Tensor& x, const Tensor&, const Tensor&, c
   return at::empty({x.size(0), x.size(1)}, x.options());
 }
 
+// ABI 13: the temporal q / k / v projection and its attention as one launch (csrc/qkv_attn.hip)
+Tensor temporal_qkv_attn_cuda(const Tensor& x, const Tensor& wqkv, const optional<Tensor>& bqkv, int64_t b, int64_t t, int64_t hw,
+                              int64_t heads, double scale) {
+  check_rows(x, "temporal_qkv_attn: x");
+  check_w(wqkv, at::kBFloat16, "temporal_qkv_attn: wqkv");
+  if (bqkv.has_value()) check_w(*bqkv, at::kFloat, "temporal_qkv_attn: bqkv");
+  const int64_t m = x.size(0), c = x.size(1);
+  TORCH_CHECK(m == b * t * hw && wqkv.dim() == 2 && wqkv.size(0) == 3 * c && wqkv.size(1) == c && c == heads * 64 &&
+              (!bqkv.has_value() || bqkv->numel() == 3 * c),
+              "temporal_qkv_attn: x [b*t*hw, c] rows, wqkv [3c, c], bqkv [3c] or None, c = heads * 64");
+  Tensor out = at::empty({m, c}, x.options());
+  TcTqaParams p{};
+  p.x = bf(x); p.wqkv = bf(wqkv); p.bqkv = bqkv.has_value() ? bqkv->data_ptr<float>() : nullptr;
+  p.out = reinterpret_cast<tc_bf16*>(out.data_ptr());
+  p.b = (int32_t)b; p.t = (int32_t)t; p.hw = (int32_t)hw; p.c = (int32_t)c; p.heads = (int32_t)heads;
+  p.ldx = (int32_t)x.stride(0); p.ldo = (int32_t)c;
+  p.scale = (float)scale;
+  check_rc(tc_temporal_qkv_attn(&p, cur_stream()), "tc_temporal_qkv_attn");
+  return out;
+}
+
+Tensor temporal_qkv_attn_meta(const Tensor& x, const Tensor&, const optional<Tensor>&, int64_t, int64_t, int64_t, int64_t, double) {
+  return at::empty({x.size(0), x.size(1)}, x.options());
+}
+
 Tensor layernorm_cuda(const Tensor& x, const Tensor& gamma, const Tensor& beta, double eps) {
   check_rows(x, "layernorm: x");
   TORCH_CHECK(x.is_contiguous(), "layernorm: x must be contiguous");
@@ -380,6 +405,7 @@ TORCH_LIBRARY(tooncrafter, m) {
   m.def("groupnorm(Tensor x, Tensor gamma, Tensor beta, int samples, int rows, float eps, bool silu) -> Tensor");
   m.def("ff_geglu_fused(Tensor x, Tensor w1, Tensor b1, Tensor w2, Tensor b2, float ln_eps) -> Tensor");
   m.def("temporal_attn_fused(Tensor x, Tensor wqkv, Tensor bqkv, Tensor wo, Tensor bo, int b, int t, int hw, int heads, float ln_eps, float scale) -> Tensor");
+  m.def("temporal_qkv_attn(Tensor x, Tensor wqkv, Tensor? bqkv, int b, int t, int hw, int heads, float scale) -> Tensor");
   m.def("layernorm(Tensor x, Tensor gamma, Tensor beta, float eps) -> Tensor");
   m.def("groupnorm_pf(Tensor x, Tensor gamma, Tensor beta, int samples, int rows, float eps, bool silu, Tensor[] prefetch) -> Tensor");
   m.def("layernorm_pf(Tensor x, Tensor gamma, Tensor beta, float eps, Tensor[] prefetch) -> Tensor");
@@ -402,6 +428,7 @@ TORCH_LIBRARY_IMPL(tooncrafter, CUDA, m) {
   m.impl("ddim_step", ddim_step_cuda);
   m.impl("ff_geglu_fused", ff_geglu_fused_cuda);
   m.impl("temporal_attn_fused", temporal_attn_fused_cuda);
+  m.impl("temporal_qkv_attn", temporal_qkv_attn_cuda);
 }
 
 TORCH_LIBRARY_IMPL(tooncrafter, Meta, m) {
@@ -417,6 +444,7 @@ TORCH_LIBRARY_IMPL(tooncrafter, Meta, m) {
   m.impl("ddim_step", ddim_step_meta);
   m.impl("ff_geglu_fused", ff_geglu_fused_meta);
   m.impl("temporal_attn_fused", temporal_attn_fused_meta);
+  m.impl("temporal_qkv_attn", temporal_qkv_attn_meta);
 }
 
 TORCH_LIBRARY_IMPL(tooncrafter, CompositeExplicitAutograd, m) {

@@ -192,6 +192,12 @@ class CrossAttention(PackedModule):
     # -- self attention over the T frames at each pixel
     def forward_temporal_self(self, x_norm, residual, act: Act, ln=None):
         pk = self.pk
+        # levels 1-3: the fused projection and the 16 x 16 attentions as ONE launch (csrc/qkv_attn.hip, ABI 13) -- the
+        # [rows, 3C] tensor between them never reaches HBM; the library's own rule decides (16 frames, hw % 8 == 0)
+        fused = getattr(ops.backend(), "temporal_qkv_attn_eligible", None) if ln is None and torch.is_tensor(x_norm) else None
+        if fused is not None and fused(b=act.b, t=act.t, hw=act.hw, c=x_norm.shape[1], heads=self.heads, ldx=x_norm.stride(0)):
+            a = ops.temporal_qkv_attn(x_norm, pk["wqkv"], None, b=act.b, t=act.t, hw=act.hw, heads=self.heads, scale=self.scale)
+            return ops.gemm(a, pk["wo"], pk["bo"], residual=residual)
         qkv = ops.gemm(x_norm, pk["wqkv"]) if ln is None else ops.gemm(x_norm, ln[0], ln[1], a_norm_eps=ln[2])
         a = ops.attention_temporal(qkv, b=act.b, t=act.t, hw=act.hw, heads=self.heads, scale=self.scale)
         return ops.gemm(a, pk["wo"], pk["bo"], residual=residual)
@@ -328,7 +334,8 @@ class BasicTransformerBlock(PackedModule):
     def _temporal_attn(self, x, i, attn, act: Act):
         """x + attn(norm<i>(x)) over the frames of every pixel.  Level 0 (C = 320, 5 heads, 16 frames): LayerNorm, qkv
         projection, the 16 x 16 attentions, output projection and the residual as ONE launch -- the [rows, 960] qkv tensor
-        and the attention output never reach HBM (csrc/tb_fused.hip); elsewhere the four launches."""
+        and the attention output never reach HBM (csrc/tb_fused.hip); elsewhere LayerNorm, then the projection and the
+        attentions as one launch (csrc/qkv_attn.hip, CrossAttention.forward_temporal_self), then the output projection."""
         fused = getattr(ops.backend(), "temporal_attn_fused_eligible", None)
         if fused is not None and fused(b=act.b, t=act.t, hw=act.hw, c=x.shape[1], heads=attn.heads, ldx=x.stride(0)):
             w, bias, eps = self._folded(i, "qkv")

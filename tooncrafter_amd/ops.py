@@ -23,7 +23,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_SILU, GATHER_CONV3x3, GATHER_CONVT3,
-                   GATHER_LINEAR, TcAttnParams, TcDdimParams, TcFfParams, TcGemmMxParams, TcGemmParams, TcTbParams)
+                   GATHER_LINEAR, TcAttnParams, TcDdimParams, TcFfParams, TcGemmMxParams, TcGemmParams, TcTbParams, TcTqaParams)
 
 BF16 = torch.bfloat16
 
@@ -325,6 +325,39 @@ class HipOps:
         p.x, p.wqkv, p.bqkv, p.wo, p.bo, p.out = (x.data_ptr(), wqkv.data_ptr(), bqkv.data_ptr(), wo.data_ptr(), bo.data_ptr(),
                                                   out.data_ptr())
         _lib.check(self.lib.tc_temporal_attn_fused(C.byref(p), _stream()), "tc_temporal_attn_fused")
+        return out
+
+    # ------------------------------------------------------------------ temporal qkv projection + attention, one launch (ABI 13)
+    def _tqa_params(self, b, t, hw, c, heads, ldx, ldo, scale):
+        p = TcTqaParams()
+        p.b, p.t, p.hw, p.c, p.heads, p.ldx, p.ldo = int(b), int(t), int(hw), int(c), int(heads), int(ldx), int(ldo)
+        p.scale = float(64 ** -0.5 if scale is None else scale)
+        return p
+
+    def temporal_qkv_attn_eligible(self, *, b, t, hw, c, heads, ldx=None) -> bool:
+        """Would `temporal_qkv_attn` be accepted?  The library's own rule (tc_temporal_qkv_attn_eligible: 16 frames,
+        c = heads * 64, hw % 8 == 0, TC_QKV_ATTN != 0); never on the MXFP8 route (which quantises the projection's input)."""
+        if self.fp8 is not None:
+            return False
+        p = self._tqa_params(b, t, hw, c, heads, c if ldx is None else ldx, c, None)
+        return bool(self.lib.tc_temporal_qkv_attn_eligible(C.byref(p)))
+
+    def temporal_qkv_attn(self, x, wqkv, bqkv=None, *, b, t, hw, heads, scale=None):
+        """Attn_frames(x . wqkv^T + bqkv) -> [rows, c] as ONE launch: `gemm(x, wqkv, bqkv)` + `attention_temporal` without the
+        [rows, 3c] tensor between them (reference attention.py:96-134 over the frames of a pixel, TemporalTransformer
+        attention.py:365-412).  x: the projection's input (LayerNorm output) rows; the result feeds to_out."""
+        m, c = x.shape
+        _dev(x, BF16, "temporal_qkv_attn x", contiguous=False)
+        _dev(wqkv, BF16, "temporal_qkv_attn wqkv")
+        if bqkv is not None:
+            _dev(bqkv, torch.float32, "temporal_qkv_attn bqkv")
+        if x.stride(1) != 1 or m != b * t * hw or tuple(wqkv.shape) != (3 * c, c) or c != heads * 64 \
+                or (bqkv is not None and bqkv.numel() != 3 * c):
+            raise ValueError("temporal_qkv_attn: x [b*t*hw, c] rows, wqkv [3c, c], bqkv [3c] or None, c = heads * 64")
+        out = torch.empty((m, c), dtype=BF16, device=x.device)
+        p = self._tqa_params(b, t, hw, c, heads, x.stride(0), c, scale)
+        p.x, p.wqkv, p.bqkv, p.out = x.data_ptr(), wqkv.data_ptr(), (None if bqkv is None else bqkv.data_ptr()), out.data_ptr()
+        _lib.check(self.lib.tc_temporal_qkv_attn(C.byref(p), _stream()), "tc_temporal_qkv_attn")
         return out
 
     # ------------------------------------------------------------------ MXFP8 GEMM path (configs[4])

@@ -91,6 +91,9 @@ class TorchLibOps(HipOps):
         return self.t.temporal_attn_fused(x, wqkv, bqkv, wo, bo, int(b), int(t), int(hw), int(heads),
                                           -1.0 if ln_eps is None else float(ln_eps), float(64 ** -0.5 if scale is None else scale))
 
+    def temporal_qkv_attn(self, x, wqkv, bqkv=None, *, b, t, hw, heads, scale=None):
+        return self.t.temporal_qkv_attn(x, wqkv, bqkv, int(b), int(t), int(hw), int(heads), float(64 ** -0.5 if scale is None else scale))
+
     def groupnorm(self, x, gamma, beta, *, samples, rows, eps, silu=False, part=None, prefetch=None, prefetch_linear=False):
         if part is not None:
             return super().groupnorm(x, gamma, beta, samples=samples, rows=rows, eps=eps, silu=silu, part=part, prefetch=prefetch,
