@@ -1,43 +1,115 @@
 #!/usr/bin/env python3
-"""Summarise a rocprofv3 (rocpd sqlite) kernel trace: per-kernel calls / total / average, and
-per-(kernel, grid) breakdown.  usage: prof_summary.py <results.db> [top_n]"""
+"""Summarise a rocprofv3 (rocpd sqlite) kernel trace of `bench.py`: per-kernel calls / total / average, per-(kernel, grid)
+breakdown, per DDIM step shares, and the GEMM-family roofline fraction recomputed from THIS file alone.
+
+usage: prof_summary.py <results.db> [top_n] [bench_stdout_log] [ddim_steps]
+
+What is in the tables: only the PRODUCT's kernels inside the product window -- from the first to the last
+kernel of libtooncrafter_hip.so (their names carry the library's anonymous namespace) -- plus the few ATen kernels the sampler
+itself launches inside that window (`randn`, `full`).  Left out, and reported in one line each so that nothing disappears
+silently: the hipBLASLt calibration matmuls of bench.py's `lease_calibration` (`Cijk_*`: not on the product path) and every
+kernel before / after the window (model build: weight synthesis and packing; the after-the-fact extras).  With
+`bench_stdout_log` (the file bench.py's JSON line went to) the lease calibration of the SAME run is printed beside the tables;
+`ddim_steps` (default 10: the trace command of scripts/gpu_r6_*.sh) sizes the algorithmic FLOPs of the run.  GEMM family:
+sum of 2 M N K over its launches = 22.661 TFLOP per guided (B = 2) forward (402 launches; the layers in front of the first
+cross-attention run once for both passes) + 57.32 TFLOP for the 16-frame and 14-frame decodes (158 launches) -- the figures
+bench.py's probe counts launch by launch and prints as `roofline.unet.algorithmic_tflop_per_unet_fwd_b2` /
+`roofline.decoder.algorithmic_tflop_16f_plus_14f`; they are properties of the model, not of a run.  Whole clip: the
+reference modules' work, 2 x 12.603 TFLOP per guided forward + 37.875 + 33.148 (1 MAC = 2 FLOP).
+"""
+import json
+import re
 import sqlite3
 import sys
 
 db = sys.argv[1]
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 25
+bench_log = sys.argv[3] if len(sys.argv) > 3 else None
+ddim_steps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+PEAK_TF = 2500.0
+TFLOP_FWD_B1, TFLOP_DEC16, TFLOP_DEC14 = 12.603, 37.875, 33.148
+GEMM_TFLOP_FWD_B2, GEMM_TFLOP_DECODES = 22.661, 57.32
+
 c = sqlite3.connect(db)
-rows = c.execute("select name, count(*), sum(duration), avg(duration) from kernels group by name order by sum(duration) desc").fetchall()
-tot = sum(r[2] for r in rows)
-s, e = c.execute("select min(start), max(end) from kernels").fetchone()
-print(f"# kernels: {sum(r[1] for r in rows)} dispatches, busy {tot/1e6:.1f} ms, first-to-last span {(e-s)/1e6:.1f} ms")
+is_product = lambda n: "anonymous namespace" in n or "_GLOBAL__N_" in n
+is_calib = lambda n: n.startswith("Cijk_")
+# the GEMM family of bench.py's `roofline`: every tc_gemm_bf16 kernel, the one-launch operators that contain projections
+GEMM_FAMILY = re.compile(r"gemm\w*_kernel|conv_halo_kernel|ff_fused_kernel|tb_fused_kernel|qkv_attn_kernel|splitk_reduce_kernel")
+
+allk = c.execute("select name, start, end, grid_x, grid_y, grid_z from kernels order by start").fetchall()
+prod = [k for k in allk if is_product(k[0])]
+if not prod:
+    sys.exit("no product kernels in the trace")
+w0, w1 = prod[0][1], max(k[2] for k in prod)
+inside = [k for k in allk if w0 <= k[1] <= w1 and not is_calib(k[0])]
+calib = [k for k in allk if is_calib(k[0])]
+outside = [k for k in allk if (k[1] < w0 or k[1] > w1) and not is_calib(k[0])]
+dur = lambda ks: sum(k[2] - k[1] for k in ks)
+
+if bench_log:
+    try:
+        for line in open(bench_log):
+            if line.startswith("{") and "lease_calibration" in line:
+                d = json.loads(line)
+                lc = d["lease_calibration"]
+                mm = [lc[k].get("matmul_8192_bf16_tflops") for k in ("before_timed_region", "after_timed_region") if lc.get(k)]
+                cp = [lc[k].get("copy_1gib_gbs") for k in ("before_timed_region", "after_timed_region") if lc.get(k)]
+                print(f"# lease calibration of this run (under the profiler): hipBLASLt 8192^3 bf16 {mm} TF/s, 1 GiB copy {cp} GB/s "
+                      f"(reference lease: 1200 TF/s, 5200 GB/s); value {d.get('value')} {d.get('unit')} at ddim_steps {ddim_steps}")
+    except (OSError, ValueError, KeyError) as e:
+        print(f"# lease calibration: not available ({type(e).__name__}: {e})")
+print(f"# product window: {len(inside)} dispatches, busy {dur(inside) / 1e6:.1f} ms, span {(w1 - w0) / 1e6:.1f} ms")
+print(f"# left out of the tables: {len(calib)} calibration matmuls (Cijk_*) {dur(calib) / 1e6:.1f} ms; "
+      f"{len(outside)} kernels outside the window (model build, extras) {dur(outside) / 1e6:.1f} ms")
+
+agg = {}
+for k in inside:
+    e = agg.setdefault(k[0], [0, 0])
+    e[0] += 1
+    e[1] += k[2] - k[1]
+tot = dur(inside)
 print(f"{'kernel':80s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>9s} {'%':>6s}")
-for r in rows[:top]:
-    print(f"{r[0][:80]:80s} {r[1]:7d} {r[2]/1e6:10.2f} {r[3]/1e3:9.1f} {100*r[2]/tot:6.1f}")
+for name, (n, d) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
+    print(f"{name[:80]:80s} {n:7d} {d / 1e6:10.2f} {d / n / 1e3:9.1f} {100 * d / tot:6.1f}")
+
+fam = [k for k in inside if GEMM_FAMILY.search(k[0])]
+tflop = ddim_steps * GEMM_TFLOP_FWD_B2 + GEMM_TFLOP_DECODES
+clip_tflop = ddim_steps * 2 * TFLOP_FWD_B1 + TFLOP_DEC16 + TFLOP_DEC14
+print(f"\n# GEMM family (gemm* / conv_halo / ff_fused / tb_fused / qkv_attn / splitk_reduce): {len(fam)} launches, {dur(fam) / 1e6:.1f} ms "
+      f"for {tflop:.1f} algorithmic TFLOP ({ddim_steps} guided forwards + 2 decodes) = {tflop / (dur(fam) / 1e9):.0f} TF/s = "
+      f"{tflop / (dur(fam) / 1e9) / PEAK_TF:.3f} of the {PEAK_TF:.0f} TF/s bf16 MFMA peak")
+print(f"# whole window: {clip_tflop:.1f} TFLOP of reference-module work over {tot / 1e6:.1f} ms of kernel-busy time = "
+      f"{clip_tflop / (tot / 1e9):.0f} TF/s = {clip_tflop / (tot / 1e9) / PEAK_TF:.3f} of peak")
+
 print("\n# per (kernel, grid) -- top 40 by total time")
-rows = c.execute("select name, grid_x, grid_y, grid_z, count(*), sum(duration), avg(duration) from kernels "
-                 "group by name, grid_x, grid_y, grid_z order by sum(duration) desc limit 40").fetchall()
-for r in rows:
-    print(f"{r[0][:60]:60s} grid({r[1]},{r[2]},{r[3]}) calls {r[4]:6d} total {r[5]/1e6:9.2f} ms avg {r[6]/1e3:9.1f} us")
+g = {}
+for k in inside:
+    e = g.setdefault((k[0], k[3], k[4], k[5]), [0, 0])
+    e[0] += 1
+    e[1] += k[2] - k[1]
+for (name, gx, gy, gz), (n, d) in sorted(g.items(), key=lambda kv: -kv[1][1])[:40]:
+    print(f"{name[:60]:60s} grid({gx},{gy},{gz}) calls {n:6d} total {d / 1e6:9.2f} ms avg {d / n / 1e3:9.1f} us")
 
 # ---- per DDIM step (between consecutive ddim_apply_kernel launches = one guided UNet forward + the step): busy time,
 # idle gaps between kernels, and the per-kernel shares averaged over the steps
-marks = [r[0] for r in c.execute("select start from kernels where name like '%ddim_apply_kernel%' order by start").fetchall()]
+marks = [k[1] for k in inside if "ddim_apply_kernel" in k[0]]
 if len(marks) >= 3:
     spans = []
-    agg = {}
+    sagg = {}
     for a, b in zip(marks[1:-1], marks[2:]):       # skip the first interval (graph capture / warm-up)
-        ks = c.execute("select name, start, end from kernels where start >= ? and start < ? order by start", (a, b)).fetchall()
-        busy = sum(k[2] - k[1] for k in ks)
+        ks = [k for k in inside if a <= k[1] < b]
+        busy = dur(ks)
         gaps = sum(max(0, ks[i + 1][1] - ks[i][2]) for i in range(len(ks) - 1))
         spans.append((b - a, busy, gaps, len(ks)))
         for k in ks:
-            e = agg.setdefault(k[0], [0, 0])
+            e = sagg.setdefault(k[0], [0, 0])
             e[0] += 1
             e[1] += k[2] - k[1]
     n = len(spans)
-    print(f"\n# per DDIM step ({n} steps between ddim_apply_kernel launches): span {sum(s[0] for s in spans)/n/1e6:.2f} ms, "
-          f"kernel-busy {sum(s[1] for s in spans)/n/1e6:.2f} ms, gaps between kernels {sum(s[2] for s in spans)/n/1e6:.2f} ms, "
-          f"{sum(s[3] for s in spans)/n:.0f} kernels")
-    for name, (cnt, dur) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
-        print(f"{name[:80]:80s} {cnt/n:7.1f} {dur/n/1e6:10.3f} ms {dur/cnt/1e3:9.1f} us {100*dur/sum(s[1] for s in spans):6.1f}")
+    fam_ms = sum(d for name, (_, d) in sagg.items() if GEMM_FAMILY.search(name)) / n / 1e6
+    print(f"\n# per DDIM step ({n} steps between ddim_apply_kernel launches): span {sum(s[0] for s in spans) / n / 1e6:.2f} ms, "
+          f"kernel-busy {sum(s[1] for s in spans) / n / 1e6:.2f} ms, gaps between kernels {sum(s[2] for s in spans) / n / 1e6:.2f} ms, "
+          f"{sum(s[3] for s in spans) / n:.0f} kernels; GEMM family {fam_ms:.2f} ms = {GEMM_TFLOP_FWD_B2 / (fam_ms / 1e3):.0f} TF/s "
+          f"= {GEMM_TFLOP_FWD_B2 / (fam_ms / 1e3) / PEAK_TF:.3f} of peak")
+    for name, (cnt, d) in sorted(sagg.items(), key=lambda kv: -kv[1][1])[:top]:
+        print(f"{name[:80]:80s} {cnt / n:7.1f} {d / n / 1e6:10.3f} ms {d / cnt / 1e3:9.1f} us {100 * d / sum(s[1] for s in spans):6.1f}")
