@@ -19,6 +19,14 @@ BF16 = torch.bfloat16
 C, HEADS, T = 320, 5, 16
 
 
+@pytest.fixture(autouse=True)
+def _fused_route_on(monkeypatch):
+    """Since round 6 the level-0 default is the three-launch chain around csrc/qkv_attn.hip (ahead of this kernel in the
+    forward-level A/B, profiles/r06_l0_chain_vs_tb_fused_forward_ab*.txt); the kernel stays in the library behind
+    TC_TB_FUSED=1 and stays tested."""
+    monkeypatch.setenv("TC_TB_FUSED", "1")
+
+
 @pytest.fixture(scope="module")
 def hip():
     from tooncrafter_amd.ops import HipOps
@@ -153,5 +161,10 @@ def test_block_routes_through_the_fused_operator(hip, monkeypatch):
             y0 = blk.forward_temporal(x, act)
         assert len(calls) == 2
         check(y1, y0, "temporal block, fused temporal attention on vs off", rel=8e-3)
+        monkeypatch.delenv("TC_TB_FUSED")                         # the default: not taken
+        n = len(calls)
+        with torch.no_grad():
+            blk.forward_temporal(x, act)
+        assert len(calls) == n
     finally:
         ops.set_backend(prev)

@@ -667,6 +667,12 @@ static int groupnorm_impl(const tc_bf16* x, tc_bf16* y, const float* gamma, cons
         else hipLaunchKernelGGL((gn_onepass_kernel<256, 13, false>), grid, dim3(256), 0, s, xb, yb, gamma, beta, rows, c, vu, eps, pf);
       }
       else done = false;
+      // (round 6: a 768-thread / 17-vector instance -- slabs of up to 204 KiB in ONE block's registers: the per-frame norms
+      // of level 0, 256 slabs = one per CU, and the clip-wide norms of level 2 -- was built, passed its tests and LOST:
+      // 38 -> 60 us, 19.5 -> 31 us, -2.1 % per guided forward (profiles/r06_gn_onepass768_bench.txt,
+      // r06_gn_onepass768_forward_ab.txt).  With one block per CU the chip reads, reduces and writes in lock-step -- no
+      // block's stores overlap another's loads -- and a CU alone draws a fraction of its share of the fabric; the three
+      // launches stream both passes at 4.4-5.5 TB/s.  Removed.)
       if (done) {
         TC_LAUNCH_CHECK();
         return TC_OK;

@@ -488,9 +488,16 @@ __global__ __launch_bounds__(TB_THREADS, 2) void tb_fused_kernel(const TbArgs p)
   tb_wait_vmcnt<0>();                               // the stream ran ahead: nothing may land in LDS after the block is gone
 }
 
-int tb_mode() {        // TC_TB_FUSED = 0 never | 1 (default) whenever the shape is the level-0 block's; read per call
+// TC_TB_FUSED = 1 whenever the shape is the level-0 block's | 0 never (the DEFAULT since round 6); read per call.
+// Rounds 4-5 shipped this kernel as the level-0 route: 1.39x the four launches it replaced (LayerNorm, qkv projection,
+// tc_attn_temporal, output projection).  Round 6's csrc/qkv_attn.hip made a better THREE-launch chain of those -- LayerNorm,
+// projection + attentions in one launch (72 us at this width where the two launches took 145), the weight-stationary
+// output projection -- and in the same-process A/B of the guided forward that chain is ahead of this kernel on both leases
+// tried: +0.57 % and +0.38 % (profiles/r06_l0_chain_vs_tb_fused_forward_ab*.txt).  This kernel is LDS-bandwidth-bound
+// (header); the chain's launches are HBM-bound and each runs near its own roof.  Kept, tested, one switch away.
+int tb_mode() {
   const char* e = getenv("TC_TB_FUSED");
-  return e ? atoi(e) : 1;
+  return e ? atoi(e) : 0;
 }
 
 }  // namespace

@@ -224,10 +224,20 @@ class CrossAttention(PackedModule):
         pk = self.pk
         c = self.heads * 64
         kv_text, kv_img = self.context_kv(ctx)
+        if kv_img is not None and self.image_cross_attention_scale != 1.0:
+            raise NotImplementedError("image_cross_attention_scale != 1.0")
+        # ABI 13: the attention projects its own query tile (to_q inside the launch, csrc/attention.hip QP): no [rows, C] query
+        # tensor, one launch less -- wherever the LayerNorm is its own launch (levels 1-3) and the library accepts the shapes
+        probe = getattr(ops.backend(), "attention_qproj_eligible", None) if ln is None and torch.is_tensor(x_norm) else None
+        if probe is not None:
+            kw = dict(batch=act.frames, heads=self.heads, lq=act.hw, lk=ctx.text_len, kv_bdiv=act.t)
+            if kv_img is not None:
+                kw.update(k2=kv_img[:, :c], v2=kv_img[:, c:], lk2=ctx.img_len, kv2_bdiv=1 if ctx.img_per_frame else act.t)
+            if probe(x_norm, pk["wq"], kv_text[:, :c], kv_text[:, c:], **kw):
+                a = ops.attention_qproj(x_norm, pk["wq"], kv_text[:, :c], kv_text[:, c:], scale=self.scale, **kw)
+                return ops.gemm(a, pk["wo"], pk["bo"], residual=residual)
         q = ops.gemm(x_norm, pk["wq"]) if ln is None else ops.gemm(x_norm, ln[0], ln[1], a_norm_eps=ln[2])
         if kv_img is not None:
-            if self.image_cross_attention_scale != 1.0:
-                raise NotImplementedError("image_cross_attention_scale != 1.0")
             # text and image softmaxes in ONE launch (attention.py:153-207 runs two attentions and adds them): Q is read
             # once and the sum is formed in fp32 registers -- no bf16 round trip of the first result through HBM
             a = ops.attention(q, kv_text[:, :c], kv_text[:, c:], batch=act.frames, heads=self.heads, lq=act.hw,
@@ -332,10 +342,10 @@ class BasicTransformerBlock(PackedModule):
         return out if share is None else (out, act)
 
     def _temporal_attn(self, x, i, attn, act: Act):
-        """x + attn(norm<i>(x)) over the frames of every pixel.  Level 0 (C = 320, 5 heads, 16 frames): LayerNorm, qkv
-        projection, the 16 x 16 attentions, output projection and the residual as ONE launch -- the [rows, 960] qkv tensor
-        and the attention output never reach HBM (csrc/tb_fused.hip); elsewhere LayerNorm, then the projection and the
-        attentions as one launch (csrc/qkv_attn.hip, CrossAttention.forward_temporal_self), then the output projection."""
+        """x + attn(norm<i>(x)) over the frames of every pixel: LayerNorm, then the q / k / v projection and the 16 x 16
+        attentions as ONE launch (csrc/qkv_attn.hip via CrossAttention.forward_temporal_self), then the output projection
+        with the residual.  Where the library offers it (TC_TB_FUSED=1, C = 320: csrc/tb_fused.hip) all of that is one launch
+        -- the default of rounds 4-5 at level 0, behind the chain above since round 6 (+0.4 ... +0.6 % per forward)."""
         fused = getattr(ops.backend(), "temporal_attn_fused_eligible", None)
         if fused is not None and fused(b=act.b, t=act.t, hw=act.hw, c=x.shape[1], heads=attn.heads, ldx=x.stride(0)):
             w, bias, eps = self._folded(i, "qkv")
