@@ -154,7 +154,6 @@ class GemmProbe:
         self.orig_ff = getattr(backend, "ff_geglu_fused", None)
         self.orig_tb = getattr(backend, "temporal_attn_fused", None)
         self.orig_tqa = getattr(backend, "temporal_qkv_attn", None)
-        self.orig_aq = getattr(backend, "attention_qproj", None)
         self.rec = []
 
     def __enter__(self):
@@ -188,16 +187,6 @@ class GemmProbe:
             self.rec.append((e0, e1, 2.0 * x.shape[0] * wqkv.shape[0] * wqkv.shape[1]))
             return out
 
-        def aq(x, wq, k, v, **kw):
-            # the cross-attention with its query projection inside (tc_attn_d64_qproj, ABI 13): counted with the family at the
-            # FLOPs of that projection and at the launch's WHOLE duration (the two softmaxes included)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = self.orig_aq(x, wq, k, v, **kw)
-            e1.record()
-            self.rec.append((e0, e1, 2.0 * x.shape[0] * wq.shape[0] * wq.shape[1]))
-            return out
-
         def gemm(a, w, bias=None, **kw):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -215,8 +204,6 @@ class GemmProbe:
             self.b.temporal_attn_fused = tb
         if self.orig_tqa is not None:
             self.b.temporal_qkv_attn = tqa
-        if self.orig_aq is not None:
-            self.b.attention_qproj = aq
         return self
 
     def __exit__(self, *a):
@@ -227,8 +214,6 @@ class GemmProbe:
             self.b.temporal_attn_fused = self.orig_tb
         if self.orig_tqa is not None:
             self.b.temporal_qkv_attn = self.orig_tqa
-        if self.orig_aq is not None:
-            self.b.attention_qproj = self.orig_aq
 
     def summary(self):
         torch.cuda.synchronize()
@@ -416,7 +401,7 @@ def measure_roofline(model, inp):
                        "a committed counter run, not measured in this process"
                        % (tj["traffic_bytes_per_forward"] / 1e9, tj.get("algorithmic_bytes_per_b2_forward", 43.2e9) / 1e9))
     return {"bound": "mfma", "kernel": "tc_gemm_bf16 family (gemm_kernel / gemm16 / gemm_wide / gemm_ws / gemm8: Linear and "
-                                       "implicit-GEMM convolutions, all gather modes; tc_ff_geglu_fused / tc_temporal_attn_fused / tc_temporal_qkv_attn / tc_attn_d64_qproj counted at the "
+                                       "implicit-GEMM convolutions, all gather modes; tc_ff_geglu_fused / tc_temporal_attn_fused / tc_temporal_qkv_attn counted at the "
                                        "FLOPs of the projections each contains and at its whole duration), UNet + decoder launches of one clip",
             "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,

@@ -222,20 +222,6 @@ typedef struct TcAttnParams {
  * lvdm/models/autoencoder_dualref.py:316,326 (and the einsum fallback attention.py:103-134). */
 int tc_attn_d64(const TcAttnParams* p, void* stream);
 
-/* ABI 13 -- tc_attn_d64 with the QUERY PROJECTION inside (reference attention.py:96 `q = self.to_q(x)` in front of the text +
- * image cross-attention of attention.py:153-207): q[b, i, h*64 + d] = sum_k x[b, i, k] * wq[h*64 + d, k], rounded to bf16 as
- * tc_gemm_bf16(x, wq) would store it, formed tile by tile in LDS -- the [rows, c] query tensor never reaches HBM and the
- * projection's launch is gone.  p->q is ignored; everything else as tc_attn_d64 (accumulate must be 0).
- *   x   bf16, element (b, i, k) at x + b*x_sb + i*x_ss + k  (the LayerNorm's output rows);   wq [heads*64, c] bf16, K contiguous;
- *   c % 64 == 0.  The host asks tc_attn_d64_qproj_eligible first (TC_ATTN_QPROJ=0: never). */
-typedef struct TcAttnQProj {
-  const tc_bf16* x; const tc_bf16* wq;
-  int64_t x_sb;
-  int32_t x_ss, c;
-} TcAttnQProj;
-int tc_attn_d64_qproj_eligible(const TcAttnParams* p, const TcAttnQProj* q);
-int tc_attn_d64_qproj(const TcAttnParams* p, const TcAttnQProj* q, void* stream);
-
 /* Temporal self-attention over <=16 frames at every pixel (attention.py:81-144 via
  * TemporalTransformer, attention.py:365-412).  qkv: fused [rows, 3*C] projection with
  * row = (b*T + t)*HW + p; columns [0,C)=q, [C,2C)=k, [2C,3C)=v, head h at h*64.

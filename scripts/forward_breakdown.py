@@ -18,7 +18,7 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 from tooncrafter_amd import ops  # noqa: E402
 
-OPS = ["gemm", "ff_geglu_fused", "temporal_attn_fused", "temporal_qkv_attn", "attention_qproj", "attention", "attention_temporal", "groupnorm", "layernorm",
+OPS = ["gemm", "ff_geglu_fused", "temporal_attn_fused", "temporal_qkv_attn", "attention", "attention_temporal", "groupnorm", "layernorm",
        "softmax_rows", "nchw_to_rows", "rows_to_nchw", "concat_rows", "repeat_rows", "timestep_embedding", "time_mix3", "gn_conv"]
 
 
@@ -42,8 +42,6 @@ def sig(name, args, kw, out):
         if kw.get("batch", 1) != 1:
             tags.append(f"x{kw['batch']}")
         return f"{m}x{w.shape[0]}x{w.shape[1]} {' '.join(tags)}", 2.0 * m * w.shape[0] * w.shape[1] * kw.get("batch", 1)
-    if name == "attention_qproj":
-        return f"{args[0].shape[0]}x{args[1].shape[0]}x{args[1].shape[1]} q+attn lk{kw.get('lk')}+{kw.get('lk2', 0)}", 2.0 * args[0].shape[0] * args[1].shape[0] * args[1].shape[1]
     if name == "temporal_qkv_attn":
         return f"{args[0].shape[0]}x{args[1].shape[0]}x{args[1].shape[1]} qkv+attn", 2.0 * args[0].shape[0] * args[1].shape[0] * args[1].shape[1]
     if name in ("groupnorm", "gn_conv"):

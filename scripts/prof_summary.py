@@ -34,8 +34,7 @@ c = sqlite3.connect(db)
 is_product = lambda n: "anonymous namespace" in n or "_GLOBAL__N_" in n
 is_calib = lambda n: n.startswith("Cijk_")
 # the GEMM family of bench.py's `roofline`: every tc_gemm_bf16 kernel, the one-launch operators that contain projections
-GEMM_FAMILY = re.compile(r"gemm\w*_kernel|conv_halo_kernel|ff_fused_kernel|tb_fused_kernel|qkv_attn_kernel|splitk_reduce_kernel|"
-                         r"attn_d64_dma_kernel<(true|false), true>")          # ... and the cross-attention that projects its own queries
+GEMM_FAMILY = re.compile(r"gemm\w*_kernel|conv_halo_kernel|ff_fused_kernel|tb_fused_kernel|qkv_attn_kernel|splitk_reduce_kernel")
 
 allk = c.execute("select name, start, end, grid_x, grid_y, grid_z from kernels order by start").fetchall()
 prod = [k for k in allk if is_product(k[0])]
@@ -76,7 +75,7 @@ for name, (n, d) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
 fam = [k for k in inside if GEMM_FAMILY.search(k[0])]
 tflop = ddim_steps * GEMM_TFLOP_FWD_B2 + GEMM_TFLOP_DECODES
 clip_tflop = ddim_steps * 2 * TFLOP_FWD_B1 + TFLOP_DEC16 + TFLOP_DEC14
-print(f"\n# GEMM family (gemm* / conv_halo / ff_fused / tb_fused / qkv_attn / attn_d64<., QP> / splitk_reduce): {len(fam)} launches, {dur(fam) / 1e6:.1f} ms "
+print(f"\n# GEMM family (gemm* / conv_halo / ff_fused / tb_fused / qkv_attn / splitk_reduce): {len(fam)} launches, {dur(fam) / 1e6:.1f} ms "
       f"for {tflop:.1f} algorithmic TFLOP ({ddim_steps} guided forwards + 2 decodes) = {tflop / (dur(fam) / 1e9):.0f} TF/s = "
       f"{tflop / (dur(fam) / 1e9) / PEAK_TF:.3f} of the {PEAK_TF:.0f} TF/s bf16 MFMA peak")
 print(f"# whole window: {clip_tflop:.1f} TFLOP of reference-module work over {tot / 1e6:.1f} ms of kernel-busy time = "

@@ -22,7 +22,7 @@ def _f(t):
 class EmuOps:
     name = "emu"
 
-    def __init__(self, round_bf16=True, ln_fusion_k=None, gn_rows=0, ff_fused_c=None, tb_fused_c=None, tqa=False, qproj=False):
+    def __init__(self, round_bf16=True, ln_fusion_k=None, gn_rows=0, ff_fused_c=None, tb_fused_c=None, tqa=False):
         self.round = round_bf16
         self.ff_fused_c = ff_fused_c         # tests only: width whose feed-forward takes the one-launch route (the library: 320)
         self.ff_fused_calls = 0
@@ -30,8 +30,6 @@ class EmuOps:
         self.tb_fused_calls = 0
         self.tqa = tqa                       # tests only: offer the qkv + attention launch (ABI 13; library: wherever c = heads * 64, t = 16, hw % 8 == 0)
         self.tqa_calls = 0
-        self.qproj = qproj                   # tests only: offer the cross-attention with its query projection inside (ABI 13)
-        self.qproj_calls = 0
         self.ln_fusion_k = ln_fusion_k       # tests only: accept a_norm_eps for EVERY consumer with this K.  The HIP library's
                                              # default rule (csrc/gemm_ws.hip: ws_shape_ok, mode 1) is narrower: K = 320, N = 320,
                                              # no GEGLU, M >= 65536 -- only the level-0 projections; TC_GEMM_WS=2 widens it to the
@@ -63,15 +61,6 @@ class EmuOps:
         qkv = self.gemm(x, wqkv, bqkv, a_norm_eps=ln_eps) if ln_eps is not None else self.gemm(x, wqkv, bqkv)
         a = self.attention_temporal(qkv, b=b, t=t, hw=hw, heads=heads, scale=scale)
         return self.gemm(a, wo, bo, residual=x)
-
-    def attention_qproj_eligible(self, x, wq, k, v, **kw):
-        return bool(self.qproj) and torch.is_tensor(x)
-
-    def attention_qproj(self, x, wq, k, v, *, batch, heads, lq, lk, kv_bdiv=1, scale=None, k2=None, v2=None, lk2=0, kv2_bdiv=1):
-        """tc_attn_d64_qproj: the roundings of the two launches it replaces (the projected queries in bf16, fp32 sums)."""
-        self.qproj_calls += 1
-        return self.attention(self.gemm(x, wq), k, v, batch=batch, heads=heads, lq=lq, lk=lk, kv_bdiv=kv_bdiv, scale=scale,
-                              k2=k2, v2=v2, lk2=lk2, kv2_bdiv=kv2_bdiv)
 
     def temporal_qkv_attn_eligible(self, *, b, t, hw, c, heads, ldx=None):
         return bool(self.tqa) and t == 16 and heads * 64 == c and hw % 8 == 0

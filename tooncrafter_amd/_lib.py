@@ -96,11 +96,6 @@ class TcTqaParams(C.Structure):
     ]
 
 
-class TcAttnQProj(C.Structure):
-    """ABI 13: the query projection inside tc_attn_d64 (tc_attn_d64_qproj)."""
-    _fields_ = [("x", C.c_void_p), ("wq", C.c_void_p), ("x_sb", C.c_int64), ("x_ss", C.c_int32), ("c", C.c_int32)]
-
-
 TC_PREFETCH_MAX = 4
 
 
@@ -154,8 +149,6 @@ SYMBOLS = {
     "tc_ff_geglu_fused": (C.c_int, [C.POINTER(TcFfParams), C.c_void_p]),
     "tc_temporal_attn_fused_eligible": (C.c_int, [C.POINTER(TcTbParams)]),
     "tc_temporal_attn_fused": (C.c_int, [C.POINTER(TcTbParams), C.c_void_p]),
-    "tc_attn_d64_qproj_eligible": (C.c_int, [C.POINTER(TcAttnParams), C.POINTER(TcAttnQProj)]),
-    "tc_attn_d64_qproj": (C.c_int, [C.POINTER(TcAttnParams), C.POINTER(TcAttnQProj), C.c_void_p]),
     "tc_temporal_qkv_attn_eligible": (C.c_int, [C.POINTER(TcTqaParams)]),
     "tc_temporal_qkv_attn": (C.c_int, [C.POINTER(TcTqaParams), C.c_void_p]),
     "tc_abi_version": (C.c_int, []),

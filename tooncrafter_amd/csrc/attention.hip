@@ -230,137 +230,23 @@ __device__ __forceinline__ u32x2 lds_read_tr16_b64(const char* p) {
 // (A three-stage K/V ring with two tiles of LDS-DMA in flight -- counted vmcnt, raw barrier, 48 KiB -- was built, bit-identical,
 // and measured 0.95-1.00x on every shape, profiles/r03_attn_ring_of_three_ab.txt: four resident blocks per CU already
 // hide the tile latency and the third stage costs one of them.  Removed.)
-// QP (ABI 13, tc_attn_d64_qproj): the block PROJECTS its 128 x 64 query tile itself -- Q = X[128 rows, C] . Wq[h*64 .. +64, C]^T,
-// the to_q of a cross-attention (reference attention.py:96, 153-207) -- on the 4-wave LDS-DMA K loop of csrc/gemm.hip (tile
-// 128 x 64 x 64, two K-steps in flight, counted vmcnt), rounds it to bf16 as the projection's own launch would, and picks
-// its fragments up from LDS: the [rows, C] query tensor never reaches HBM and the projection's launch is gone.  Blocks are
-// dealt so that the heads of one query tile run back to back on one XCD (its L2 serves the X re-reads).
-constexpr int QP_A_BYTES = 128 * 128, QP_STAGE = (128 + 64) * 128;        // A 16 KiB + W 8 KiB per stage
-constexpr int QP_Q_OFF = 2 * DMA_STAGE;                                    // the projected tile: [128][64] bf16 behind the K / V stages
-constexpr int QP_LDS = QP_Q_OFF + 128 * 128;                               // 48 KiB (>= the two projection stages)
-static_assert(2 * QP_STAGE <= QP_LDS, "projection stages live in the attention's LDS");
-struct QpArgs {
-  const bf16_t* x; const bf16_t* wq;
-  int64_t x_sb;
-  int x_ss, c, tiles_q, units;
-};
-
-template <int N>
-__device__ __forceinline__ void attn_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-template <bool DUAL, bool QP = false>
-__global__ __launch_bounds__(256) void attn_d64_dma_kernel(const TcAttnParams p, const QpArgs qp = QpArgs{}) {
-  __shared__ __attribute__((aligned(1024))) char smem[QP ? QP_LDS : 2 * DMA_STAGE];
+template <bool DUAL>
+__global__ __launch_bounds__(256) void attn_d64_dma_kernel(const TcAttnParams p) {
+  __shared__ __attribute__((aligned(1024))) char smem[2 * DMA_STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int l31 = lane & 31, half = lane >> 5;
-  int b = blockIdx.z, h = blockIdx.y, qt = blockIdx.x;
-  if constexpr (QP) {
-    // 1-D grid: XCD x (= blockIdx & 7) walks the (batch, query tile) units x, x + 8, ..., all heads of a unit back to back
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int unit = (slot / p.heads) * 8 + xcd;
-    h = slot - (slot / p.heads) * p.heads;
-    if (unit >= qp.units) return;
-    b = unit / qp.tiles_q;
-    qt = unit - b * qp.tiles_q;
-  }
+  const int b = blockIdx.z, h = blockIdx.y;
   const bf16_t* qb = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.q_sb + h * 64;
   bf16_t* ob = reinterpret_cast<bf16_t*>(p.o) + (int64_t)b * p.o_sb + h * 64;
 
-  const int q_row = qt * 128 + wave * 32 + l31;
+  const int q_row = blockIdx.x * 128 + wave * 32 + l31;
   const int q_ld = q_row < p.lq ? q_row : p.lq - 1;   // clamp: tail rows compute garbage, never stored
   bf16x8 qf[4];
-  if constexpr (QP) {
-    const int lrow = tid >> 3;
-    const int chunk = (tid & 7) ^ ((lrow >> 1) & 7);
-    const int row0 = qt * 128;
-    const int valid = min(128, p.lq - row0);                     // rows of the tile that exist: the rest read zeros (offset >= extent)
-    const tc_rsrc_t a_rsrc = make_rsrc(qp.x + (int64_t)b * qp.x_sb + (int64_t)row0 * qp.x_ss, ((int64_t)(valid - 1) * qp.x_ss + qp.c) * 2);
-    const tc_rsrc_t w_rsrc = make_rsrc(qp.wq + (int64_t)h * 64 * qp.c, (int64_t)64 * qp.c * 2);
-    uint32_t a_voff[4], b_voff[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a_voff[i] = (uint32_t)((lrow + 32 * i) * qp.x_ss * 2 + chunk * 16);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) b_voff[i] = (uint32_t)((lrow + 32 * i) * qp.c * 2 + chunk * 16);
-    auto load_tile = [&](int kb, int stage) {
-      const uint32_t soff = (uint32_t)kb * 128u;
-      char* sa = smem + stage * QP_STAGE + wave_u * 1024;
-      char* sb = sa + QP_A_BYTES;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) glds16(w_rsrc, sb + i * 4096, b_voff[i], soff);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) glds16(a_rsrc, sa + i * 4096, a_voff[i], soff);
-    };
-    f32x16 qacc[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) qacc[j][r] = 0.f;
-    auto compute = [&](int stage) {                              // wave w: rows 32 w .. +32, both 32-column blocks
-      const char* sa = smem + stage * QP_STAGE;
-      const char* sb = sa + QP_A_BYTES;
-      bf16x8 af[2], bf[2][2];
-      auto frags = [&](int kk, bf16x8& a, bf16x8 (&bb)[2]) {
-        const int c = kk * 2 + half;
-        a = *reinterpret_cast<const bf16x8*>(sa + lds_off(wave * 32 + l31, c));
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bb[j] = *reinterpret_cast<const bf16x8*>(sb + lds_off(j * 32 + l31, c));
-      };
-      auto mfmas = [&](const bf16x8& a, const bf16x8 (&bb)[2]) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) qacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb[j], qacc[j], 0, 0, 0);
-      };
-      frags(0, af[0], bf[0]);
-      frags(1, af[1], bf[1]);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(af[0], bf[0]);
-      __builtin_amdgcn_sched_barrier(0);
-      frags(2, af[0], bf[0]);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(af[1], bf[1]);
-      __builtin_amdgcn_sched_barrier(0);
-      frags(3, af[1], bf[1]);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(af[0], bf[0]);
-      mfmas(af[1], bf[1]);
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    const int nk = qp.c / 64;
-    load_tile(0, 0);
-    if (nk > 1) load_tile(1, 1);
-    for (int kb = 0; kb < nk; ++kb) {
-      const int st = kb & 1;
-      if (kb + 1 < nk) attn_wait_vmcnt<6>();
-      else attn_wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      compute(st);
-      if (kb + 2 < nk) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        load_tile(kb + 2, st);
-      }
-    }
-    __syncthreads();                                             // every wave is done with the stages: Q overwrites part of them
-    // accumulator register r of a lane = row (r & 3) + 8 (r >> 2) + 4 half of the wave's 32, column 32 j + l31 -> bf16, row-major
-    // [128][64] with the chunk swizzle of the fragment reads; a wave writes and re-reads its OWN 32 rows only
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int col = j * 32 + l31;
-        *reinterpret_cast<bf16_t*>(smem + QP_Q_OFF + row * 128 + (((col >> 3) ^ ((row >> 1) & 7)) << 4) + (col & 7) * 2) = (bf16_t)qacc[j][r];
-      }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-      qf[kk] = *reinterpret_cast<const bf16x8*>(smem + QP_Q_OFF + lds_off(wave * 32 + l31, kk * 2 + half));
-  } else {
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-      qf[kk] = *reinterpret_cast<const bf16x8*>(qb + (int64_t)q_ld * p.q_ss + kk * 16 + half * 8);
-  }
+  for (int kk = 0; kk < 4; ++kk)
+    qf[kk] = *reinterpret_cast<const bf16x8*>(qb + (int64_t)q_ld * p.q_ss + kk * 16 + half * 8);
 
   // ---- fragment read offsets (per lane, fixed for the whole kernel)
   // K (A operand of S^T = K Q^T): lane (key l31 of block kbk, k = 16 kk + 8 half ..): 16-byte chunk 2 kk + half of its row
@@ -633,47 +519,6 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const bf16_t* __rest
 
 }  // namespace
 
-// ABI 13: would tc_attn_d64_qproj take this problem?  (TC_ATTN_QPROJ=0: never; read per call)
-extern "C" int tc_attn_d64_qproj_eligible(const TcAttnParams* pp, const TcAttnQProj* qq) {
-  if (!pp || !qq) return 0;
-  const char* e = getenv("TC_ATTN_QPROJ");
-  if (e && e[0] == '0') return 0;
-  const TcAttnParams& p = *pp;
-  if (p.batch <= 0 || p.heads <= 0 || p.lq <= 0 || p.lk <= 0 || p.kv_bdiv <= 0 || p.accumulate) return 0;
-  if (qq->c <= 0 || (qq->c & 63) || qq->x_ss < qq->c || (qq->x_ss & 7) || (qq->x_sb & 7)) return 0;
-  if ((int64_t)128 * qq->x_ss * 2 >= 0x7fffff00LL || (int64_t)64 * qq->c * 2 >= 0x7fffff00LL) return 0;
-  const bool fits = (int64_t)p.lk * p.k_ss * 2 < 0x7fffff00LL && (int64_t)p.lk * p.v_ss * 2 < 0x7fffff00LL && p.k_ss >= 64 && p.v_ss >= 64;
-  if (!fits) return 0;
-  if (p.k2) {
-    if (!p.v2 || p.lk2 <= 0 || p.kv2_bdiv <= 0) return 0;
-    if (!((int64_t)p.lk2 * p.k2_ss * 2 < 0x7fffff00LL && (int64_t)p.lk2 * p.v2_ss * 2 < 0x7fffff00LL && p.k2_ss >= 64 && p.v2_ss >= 64)) return 0;
-  }
-  const int64_t units = (int64_t)p.batch * ((p.lq + 127) / 128);
-  if ((int64_t)p.heads * 8 * ((units + 7) / 8) > 0x7fffffffLL) return 0;
-  return 1;
-}
-
-extern "C" int tc_attn_d64_qproj(const TcAttnParams* pp, const TcAttnQProj* qq, void* stream) {
-  if (!pp || !qq) return TC_EINVAL;
-  const TcAttnParams& p = *pp;
-  if (!qq->x || !qq->wq || !p.k || !p.v || !p.o) return TC_EINVAL;
-  if (!tc_attn_d64_qproj_eligible(pp, qq)) return TC_ESHAPE;
-  if (!tc_aligned16(qq->x) || !tc_aligned16(qq->wq) || !tc_aligned16(p.k) || !tc_aligned16(p.v) || !tc_aligned16(p.o)) return TC_EALIGN;
-  if ((p.k_ss & 7) || (p.v_ss & 7) || (p.o_ss & 7) || (p.k_sb & 7) || (p.v_sb & 7) || (p.o_sb & 7)) return TC_EALIGN;
-  const bool dual = p.k2 != nullptr;
-  if (dual && (!tc_aligned16(p.k2) || !tc_aligned16(p.v2) || (p.k2_ss & 7) || (p.v2_ss & 7) || (p.k2_sb & 7) || (p.v2_sb & 7))) return TC_EALIGN;
-  QpArgs a;
-  a.x = reinterpret_cast<const bf16_t*>(qq->x); a.wq = reinterpret_cast<const bf16_t*>(qq->wq);
-  a.x_sb = qq->x_sb; a.x_ss = qq->x_ss; a.c = qq->c;
-  a.tiles_q = (p.lq + 127) / 128;
-  a.units = p.batch * a.tiles_q;
-  const dim3 grid((unsigned)(p.heads * 8 * ((a.units + 7) / 8))), block(256);
-  if (dual) hipLaunchKernelGGL((attn_d64_dma_kernel<true, true>), grid, block, 0, reinterpret_cast<hipStream_t>(stream), p, a);
-  else hipLaunchKernelGGL((attn_d64_dma_kernel<false, true>), grid, block, 0, reinterpret_cast<hipStream_t>(stream), p, a);
-  TC_LAUNCH_CHECK();
-  return TC_OK;
-}
-
 extern "C" int tc_attn_d64(const TcAttnParams* pp, void* stream) {
   if (!pp) return TC_EINVAL;
   const TcAttnParams& p = *pp;
@@ -698,9 +543,9 @@ extern "C" int tc_attn_d64(const TcAttnParams* pp, void* stream) {
     const bool fits2 = (int64_t)p.lk2 * p.k2_ss * 2 < 0x7fffff00LL && (int64_t)p.lk2 * p.v2_ss * 2 < 0x7fffff00LL &&
                        p.k2_ss >= 64 && p.v2_ss >= 64;
     if (!fits || !fits2) return TC_ESHAPE;
-    hipLaunchKernelGGL((attn_d64_dma_kernel<true, false>), grid, block, 0, reinterpret_cast<hipStream_t>(stream), p, QpArgs{});
+    hipLaunchKernelGGL(attn_d64_dma_kernel<true>, grid, block, 0, reinterpret_cast<hipStream_t>(stream), p);
   } else if (!use_reg && fits) {
-    hipLaunchKernelGGL((attn_d64_dma_kernel<false, false>), grid, block, 0, reinterpret_cast<hipStream_t>(stream), p, QpArgs{});
+    hipLaunchKernelGGL(attn_d64_dma_kernel<false>, grid, block, 0, reinterpret_cast<hipStream_t>(stream), p);
   } else {
     hipLaunchKernelGGL(attn_d64_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream), p);
   }

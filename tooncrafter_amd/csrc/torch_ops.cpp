@@ -324,45 +324,6 @@ Tensor temporal_attn_fused_meta(const Tensor& x, const Tensor&, const Tensor&, c
   return at::empty({x.size(0), x.size(1)}, x.options());
 }
 
-// ABI 13: tc_attn_d64 with the query projection inside (x [batch*lq, c] rows, wq [heads*64, c])
-Tensor attention_qproj_cuda(const Tensor& x, const Tensor& wq, const Tensor& k, const Tensor& v, int64_t batch, int64_t heads, int64_t lq,
-                            int64_t lk, int64_t kv_bdiv, double scale, const optional<Tensor>& k2, const optional<Tensor>& v2, int64_t lk2,
-                            int64_t kv2_bdiv) {
-  check_rows(x, "attention_qproj: x"); check_rows(k, "attention_qproj: k"); check_rows(v, "attention_qproj: v");
-  check_w(wq, at::kBFloat16, "attention_qproj: wq");
-  const int64_t hd = heads * 64, c = x.size(1);
-  TORCH_CHECK(x.size(0) == batch * lq && wq.dim() == 2 && wq.size(0) == hd && wq.size(1) == c && k.size(1) == hd && v.size(1) == hd,
-              "attention_qproj: x [batch*lq, c] rows, wq [heads*64, c], k / v [.., heads*64]");
-  const int64_t kvb = (batch + kv_bdiv - 1) / kv_bdiv;
-  TORCH_CHECK(k.size(0) == kvb * lk && v.size(0) == kvb * lk, "attention_qproj: K/V rows != kv_batches * lk");
-  Tensor out = at::empty({batch * lq, hd}, x.options());
-  TcAttnParams p = {};
-  p.q = nullptr; p.k = bf(k); p.v = bf(v); p.o = reinterpret_cast<tc_bf16*>(out.data_ptr());
-  p.batch = (int32_t)batch; p.heads = (int32_t)heads; p.lq = (int32_t)lq; p.lk = (int32_t)lk;
-  p.q_ss = (int32_t)hd; p.k_ss = (int32_t)k.stride(0); p.v_ss = (int32_t)v.stride(0); p.o_ss = (int32_t)out.stride(0);
-  p.q_sb = lq * hd; p.k_sb = lk * k.stride(0); p.v_sb = lk * v.stride(0); p.o_sb = lq * out.stride(0);
-  p.kv_bdiv = (int32_t)kv_bdiv; p.scale = (float)scale;
-  if (k2.has_value()) {
-    TORCH_CHECK(v2.has_value() && lk2 > 0 && kv2_bdiv > 0, "attention_qproj: second K/V set incomplete");
-    check_rows(*k2, "attention_qproj: k2"); check_rows(*v2, "attention_qproj: v2");
-    const int64_t kvb2 = (batch + kv2_bdiv - 1) / kv2_bdiv;
-    TORCH_CHECK(k2->size(0) == kvb2 * lk2 && v2->size(0) == kvb2 * lk2 && k2->size(1) == hd && v2->size(1) == hd,
-                "attention_qproj: second K/V set must be [(batch / kv2_bdiv) * lk2, heads * 64]");
-    p.k2 = bf(*k2); p.v2 = bf(*v2); p.lk2 = (int32_t)lk2; p.kv2_bdiv = (int32_t)kv2_bdiv;
-    p.k2_ss = (int32_t)k2->stride(0); p.v2_ss = (int32_t)v2->stride(0);
-    p.k2_sb = lk2 * k2->stride(0); p.v2_sb = lk2 * v2->stride(0);
-  }
-  TcAttnQProj qp = {};
-  qp.x = bf(x); qp.wq = bf(wq); qp.x_sb = lq * x.stride(0); qp.x_ss = (int32_t)x.stride(0); qp.c = (int32_t)c;
-  check_rc(tc_attn_d64_qproj(&p, &qp, cur_stream()), "tc_attn_d64_qproj");
-  return out;
-}
-
-Tensor attention_qproj_meta(const Tensor& x, const Tensor&, const Tensor&, const Tensor&, int64_t batch, int64_t heads, int64_t lq, int64_t,
-                            int64_t, double, const optional<Tensor>&, const optional<Tensor>&, int64_t, int64_t) {
-  return at::empty({batch * lq, heads * 64}, x.options());
-}
-
 // ABI 13: the temporal q / k / v projection and its attention as one launch (csrc/qkv_attn.hip)
 Tensor temporal_qkv_attn_cuda(const Tensor& x, const Tensor& wqkv, const optional<Tensor>& bqkv, int64_t b, int64_t t, int64_t hw,
                               int64_t heads, double scale) {
@@ -440,8 +401,6 @@ TORCH_LIBRARY(tooncrafter, m) {
         "int row_div, int act, float alpha, float out_scale, bool out_f32, int[] conv) -> Tensor");
   m.def("attention(Tensor q, Tensor k, Tensor v, int batch, int heads, int lq, int lk, int kv_bdiv, float scale, "
         "Tensor? k2, Tensor? v2, int lk2, int kv2_bdiv) -> Tensor");
-  m.def("attention_qproj(Tensor x, Tensor wq, Tensor k, Tensor v, int batch, int heads, int lq, int lk, int kv_bdiv, float scale, "
-        "Tensor? k2, Tensor? v2, int lk2, int kv2_bdiv) -> Tensor");
   m.def("attention_temporal(Tensor qkv, int b, int t, int hw, int heads, float scale) -> Tensor");
   m.def("groupnorm(Tensor x, Tensor gamma, Tensor beta, int samples, int rows, float eps, bool silu) -> Tensor");
   m.def("ff_geglu_fused(Tensor x, Tensor w1, Tensor b1, Tensor w2, Tensor b2, float ln_eps) -> Tensor");
@@ -461,7 +420,6 @@ TORCH_LIBRARY_IMPL(tooncrafter, CUDA, m) {
   m.impl("quant_mxfp8", quant_mxfp8_cuda);
   m.impl("gemm_mx", gemm_mx_cuda);
   m.impl("attention", attention_cuda);
-  m.impl("attention_qproj", attention_qproj_cuda);
   m.impl("attention_temporal", attention_temporal_cuda);
   m.impl("groupnorm", groupnorm_cuda);
   m.impl("layernorm", layernorm_cuda);
@@ -478,7 +436,6 @@ TORCH_LIBRARY_IMPL(tooncrafter, Meta, m) {
   m.impl("quant_mxfp8", quant_mxfp8_meta);
   m.impl("gemm_mx", gemm_mx_meta);
   m.impl("attention", attention_meta);
-  m.impl("attention_qproj", attention_qproj_meta);
   m.impl("attention_temporal", attention_temporal_meta);
   m.impl("groupnorm", like_meta3);
   m.impl("layernorm", like_meta_ln);

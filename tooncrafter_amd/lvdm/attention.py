@@ -226,16 +226,6 @@ class CrossAttention(PackedModule):
         kv_text, kv_img = self.context_kv(ctx)
         if kv_img is not None and self.image_cross_attention_scale != 1.0:
             raise NotImplementedError("image_cross_attention_scale != 1.0")
-        # ABI 13: the attention projects its own query tile (to_q inside the launch, csrc/attention.hip QP): no [rows, C] query
-        # tensor, one launch less -- wherever the LayerNorm is its own launch (levels 1-3) and the library accepts the shapes
-        probe = getattr(ops.backend(), "attention_qproj_eligible", None) if ln is None and torch.is_tensor(x_norm) else None
-        if probe is not None:
-            kw = dict(batch=act.frames, heads=self.heads, lq=act.hw, lk=ctx.text_len, kv_bdiv=act.t)
-            if kv_img is not None:
-                kw.update(k2=kv_img[:, :c], v2=kv_img[:, c:], lk2=ctx.img_len, kv2_bdiv=1 if ctx.img_per_frame else act.t)
-            if probe(x_norm, pk["wq"], kv_text[:, :c], kv_text[:, c:], **kw):
-                a = ops.attention_qproj(x_norm, pk["wq"], kv_text[:, :c], kv_text[:, c:], scale=self.scale, **kw)
-                return ops.gemm(a, pk["wo"], pk["bo"], residual=residual)
         q = ops.gemm(x_norm, pk["wq"]) if ln is None else ops.gemm(x_norm, ln[0], ln[1], a_norm_eps=ln[2])
         if kv_img is not None:
             # text and image softmaxes in ONE launch (attention.py:153-207 runs two attentions and adds them): Q is read

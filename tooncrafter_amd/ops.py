@@ -23,7 +23,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_SILU, GATHER_CONV3x3, GATHER_CONVT3,
-                   GATHER_LINEAR, TcAttnParams, TcDdimParams, TcAttnQProj, TcFfParams, TcGemmMxParams, TcGemmParams, TcTbParams, TcTqaParams)
+                   GATHER_LINEAR, TcAttnParams, TcDdimParams, TcFfParams, TcGemmMxParams, TcGemmParams, TcTbParams, TcTqaParams)
 
 BF16 = torch.bfloat16
 
@@ -433,60 +433,6 @@ class HipOps:
         _lib.check(self.lib.tc_gemm_mxfp8(C.byref(px), _stream()), "tc_gemm_mxfp8")
 
     # ------------------------------------------------------------------ attention
-    def _attn_params(self, q, k, v, out, *, batch, heads, lq, lk, kv_bdiv, accumulate, scale, k2, v2, lk2, kv2_bdiv):
-        hd = heads * 64
-        p = TcAttnParams()
-        p.q, p.k, p.v, p.o = (0 if q is None else q.data_ptr()), k.data_ptr(), v.data_ptr(), out.data_ptr()
-        p.batch, p.heads, p.lq, p.lk = batch, heads, lq, lk
-        p.q_ss, p.k_ss, p.v_ss, p.o_ss = (hd if q is None else q.stride(0)), k.stride(0), v.stride(0), out.stride(0)
-        p.q_sb, p.k_sb, p.v_sb, p.o_sb = lq * p.q_ss, lk * k.stride(0), lk * v.stride(0), lq * out.stride(0)
-        p.kv_bdiv = kv_bdiv
-        p.accumulate = 1 if accumulate else 0
-        p.scale = float(scale if scale is not None else 64 ** -0.5)
-        if k2 is not None:
-            kvb2 = (batch + kv2_bdiv - 1) // kv2_bdiv
-            if lk2 <= 0 or k2.shape != (kvb2 * lk2, hd) or v2.shape != (kvb2 * lk2, hd):
-                raise ValueError("attention: second K/V set must be [(batch//kv2_bdiv)*lk2, heads*64]")
-            p.k2, p.v2, p.lk2, p.kv2_bdiv = k2.data_ptr(), v2.data_ptr(), lk2, kv2_bdiv
-            p.k2_ss, p.v2_ss = k2.stride(0), v2.stride(0)
-            p.k2_sb, p.v2_sb = lk2 * k2.stride(0), lk2 * v2.stride(0)
-        return p
-
-    def _qproj_args(self, x, wq, k, v, heads, batch, lq, lk, kv_bdiv, k2, v2, lk2, kv2_bdiv):
-        x, k, v = _rows_view(x), _rows_view(k), _rows_view(v)
-        if k2 is not None:
-            k2, v2 = _rows_view(k2), _rows_view(v2)
-        hd, c = heads * 64, x.shape[1]
-        _dev(wq, BF16, "attention_qproj wq")
-        kvb = (batch + kv_bdiv - 1) // kv_bdiv
-        if x.shape[0] != batch * lq or tuple(wq.shape) != (hd, c) or k.shape != (kvb * lk, hd) or v.shape != (kvb * lk, hd):
-            raise ValueError("attention_qproj: x [batch*lq, c] rows, wq [heads*64, c], k / v [(batch//kv_bdiv)*lk, heads*64]")
-        qp = TcAttnQProj()
-        qp.x, qp.wq, qp.x_sb, qp.x_ss, qp.c = x.data_ptr(), wq.data_ptr(), lq * x.stride(0), x.stride(0), c
-        return x, k, v, k2, v2, qp
-
-    def attention_qproj_eligible(self, x, wq, k, v, *, batch, heads, lq, lk, kv_bdiv=1, k2=None, v2=None, lk2=0, kv2_bdiv=1) -> bool:
-        """Would `attention_qproj` be accepted?  The library's own rule (tc_attn_d64_qproj_eligible; TC_ATTN_QPROJ=0: never);
-        never on the MXFP8 route (x may arrive quantised there)."""
-        if self.fp8 is not None or not torch.is_tensor(x):
-            return False
-        x, k, v, k2, v2, qp = self._qproj_args(x, wq, k, v, heads, batch, lq, lk, kv_bdiv, k2, v2, lk2, kv2_bdiv)
-        p = self._attn_params(None, k, v, k, batch=batch, heads=heads, lq=lq, lk=lk, kv_bdiv=kv_bdiv, accumulate=False, scale=None,
-                              k2=k2, v2=v2, lk2=lk2, kv2_bdiv=kv2_bdiv)
-        return bool(self.lib.tc_attn_d64_qproj_eligible(C.byref(p), C.byref(qp)))
-
-    def attention_qproj(self, x, wq, k, v, *, batch, heads, lq, lk, kv_bdiv=1, scale=None, k2=None, v2=None, lk2=0, kv2_bdiv=1):
-        """`attention(gemm(x, wq), k, v, ...)` as ONE launch (ABI 13, tc_attn_d64_qproj): the cross-attention projects its own
-        query tile (reference attention.py:96 to_q in front of attention.py:153-207); the [rows, C] query tensor never
-        reaches HBM.  x: [batch*lq, c] rows (the LayerNorm's output), wq: [heads*64, c]."""
-        x, k, v, k2, v2, qp = self._qproj_args(x, wq, k, v, heads, batch, lq, lk, kv_bdiv, k2, v2, lk2, kv2_bdiv)
-        _dev(x, BF16, "attention_qproj x", contiguous=False)
-        out = torch.empty((batch * lq, heads * 64), dtype=BF16, device=x.device)
-        p = self._attn_params(None, k, v, out, batch=batch, heads=heads, lq=lq, lk=lk, kv_bdiv=kv_bdiv, accumulate=False,
-                              scale=scale, k2=k2, v2=v2, lk2=lk2, kv2_bdiv=kv2_bdiv)
-        _lib.check(self.lib.tc_attn_d64_qproj(C.byref(p), C.byref(qp), _stream()), "tc_attn_d64_qproj")
-        return out
-
     def attention(self, q, k, v, *, batch, heads, lq, lk, kv_bdiv=1, out=None, accumulate=False, scale=None,
                   k2=None, v2=None, lk2=0, kv2_bdiv=1):
         """q: [batch*lq, heads*64] rows view; k, v: [(batch//kv_bdiv)*lk, heads*64] rows views.

@@ -81,10 +81,6 @@ class TorchLibOps(HipOps):
         return self.t.attention(q, k, v, batch, heads, lq, lk, kv_bdiv, float(64 ** -0.5 if scale is None else scale),
                                 k2, v2, int(lk2), int(kv2_bdiv))
 
-    def attention_qproj(self, x, wq, k, v, *, batch, heads, lq, lk, kv_bdiv=1, scale=None, k2=None, v2=None, lk2=0, kv2_bdiv=1):
-        return self.t.attention_qproj(x, wq, k, v, batch, heads, lq, lk, kv_bdiv, float(64 ** -0.5 if scale is None else scale),
-                                      k2, v2, int(lk2), int(kv2_bdiv))
-
     def attention_temporal(self, qkv, *, b, t, hw, heads, scale=None):
         return self.t.attention_temporal(qkv, b, t, hw, heads, float(64 ** -0.5 if scale is None else scale))
 
