@@ -308,7 +308,7 @@ def measure_roofline_hbm(model, inp):
             dec.use_hipgraph = was
     gbs = by / (ms * 1e-3) / 1e9
     dgbs = dby / (dms * 1e-3) / 1e9
-    name, tj = _pmc_file("r05_pmc_gn_traffic.json", "r04_pmc_gn_traffic.json", "r03_pmc_gn_traffic.json")
+    name, tj = _pmc_file("r06_pmc_gn_traffic.json", "r05_pmc_gn_traffic.json", "r04_pmc_gn_traffic.json", "r03_pmc_gn_traffic.json")
     traffic = round(tj["traffic_bytes_per_launch"]) if tj is not None else None
     return {"bound": "hbm", "kernel": "tc_groupnorm (GroupNorm32 + SiLU over channels-last rows)",
             "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
@@ -393,7 +393,7 @@ def measure_roofline(model, inp):
     # HBM-side bytes per launch come from a separate rocprofv3 --pmc run of the same forward (counters cannot
     # be read from inside this process); the committed summary of that run is quoted with its provenance
     traffic, traffic_src = None, None
-    name, tj = _pmc_file("r05_pmc_unet_traffic.json", "r04_pmc_unet_traffic.json", "r03_pmc_unet_traffic.json", "r02_pmc_unet_traffic.json", "r01_v6_pmc_unet_traffic.json")
+    name, tj = _pmc_file("r06_pmc_unet_traffic.json", "r05_pmc_unet_traffic.json", "r04_pmc_unet_traffic.json", "r03_pmc_unet_traffic.json", "r02_pmc_unet_traffic.json", "r01_v6_pmc_unet_traffic.json")
     if tj is not None:
         traffic = round(tj["traffic_bytes_per_launch"])
         traffic_src = (f"profiles/{name}: (2*FETCH_SIZE + WRITE_SIZE) per tc_gemm_bf16 launch of a B=2 UNet forward, bytes; "

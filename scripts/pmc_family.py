@@ -10,6 +10,7 @@ FAMS = [("gemm_kernel<0", "linear, 128^2 / 64^2 tiles"), ("gemm_kernel<1", "3x3 
         ("gemm_kernel<2", "temporal conv, 128^2 / 64^2 tiles"), ("gemm16_kernel", "160^2 tiles"), ("conv_halo_kernel", "3x3 conv, halo patches"),
         ("gemm8_kernel", "8-wave 256^2"), ("gemm_wide_kernel", "256-row tiles"), ("gemm_ws_kernel", "K = 320 weight-stationary"),
         ("ff_fused_kernel", "level-0 feed-forward, one launch"), ("tb_fused_kernel", "level-0 temporal attention, one launch"),
+        ("qkv_attn_kernel", "temporal qkv projection + attention, one launch"),
         ("attn_d64", "attention d = 64"), ("attn_temporal", "temporal attention"), ("gn_", "GroupNorm"), ("layernorm", "LayerNorm"),
         ("splitk_reduce", "split-K reduction")]
 

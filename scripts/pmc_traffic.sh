@@ -2,7 +2,7 @@
 # HBM-side traffic of the GEMM family and of GroupNorm in a B=2 UNet forward, for bench.py's roofline.traffic /
 # roofline_hbm.traffic: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes
 # (MI355X_MICROARCH.md, HBM section; never together with sys/hip/hsa tracing) over scripts/pmc_unet.py.
-#   usage: scripts/pmc_traffic.sh TAG [forwards]   -> gpurun_out/TAG/r05_pmc_{unet,gn}_traffic.json
+#   usage: scripts/pmc_traffic.sh TAG [forwards]   -> gpurun_out/TAG/r06_pmc_{unet,gn}_traffic.json
 set -u
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 TAG=$1; N=${2:-2}
