@@ -12,22 +12,13 @@ print("TC_GN_BLOCKS", os.environ.get("TC_GN_BLOCKS"))
 
 
 def gn(samples, rows, c, tag):
-    """Three arms, interleaved in one process: TC_GN_COOP=0 (one-pass where a slab fits a block, else three launches), the
-    default routing, TC_GN_COOP=2 (the cooperative kernel wherever a plan exists).  TB/s on the ALGORITHMIC bytes (2 B read +
-    2 B written per element), the figure bench.py's roofline_hbm quotes."""
+    """TB/s on the ALGORITHMIC bytes (2 B read + 2 B written per element), the figure bench.py's roofline_hbm quotes.  (Rounds 5 / 6
+    compared this routing with a cooperative single-launch kernel and with 768-thread one-pass blocks here; both lost and are gone:
+    profiles/r05_gn_coop_bench.txt, r06_gn_onepass768_bench.txt.)"""
     x = torch.randn(samples * rows, c, device=dev).to(BF)
     g, b = torch.ones(c, device=dev), torch.zeros(c, device=dev)
-    out = []
-    for mode in ("0", None, "2"):
-        if mode is None:
-            os.environ.pop("TC_GN_COOP", None)
-        else:
-            os.environ["TC_GN_COOP"] = mode
-        grid = hip.lib.tc_groupnorm_coop_grid(samples, rows, c)
-        ms = timeit(lambda: hip.groupnorm(x, g, b, samples=samples, rows=rows, eps=1e-5, silu=True))
-        out.append(f"{ms*1e3:7.1f} us {4.0*x.numel()/ms/1e9:5.2f} TB/s" + (f" (coop grid {grid})" if grid else " (no coop)"))
-    os.environ.pop("TC_GN_COOP", None)
-    print(f"groupnorm {tag:18s} s={samples:3d} rows={rows:7d} c={c:5d} | base {out[0]} | default {out[1]} | coop {out[2]}")
+    ms = timeit(lambda: hip.groupnorm(x, g, b, samples=samples, rows=rows, eps=1e-5, silu=True))
+    print(f"groupnorm {tag:18s} s={samples:3d} rows={rows:7d} c={c:5d} | {ms*1e3:7.1f} us {4.0*x.numel()/ms/1e9:5.2f} TB/s")
 
 
 def ln(rows, c, tag):

@@ -6,6 +6,8 @@ import sys
 
 import torch
 
+os.environ.setdefault("TC_TB_FUSED", "1")   # opt-in since round 6 (the level-0 default is the chain around csrc/qkv_attn.hip)
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tooncrafter_amd.lvdm.common import pack_linear  # noqa: E402
 from tooncrafter_amd.ops import HipOps  # noqa: E402

@@ -1,5 +1,7 @@
 """`torch.ops.tooncrafter.*` (TORCH_LIBRARY layer, csrc/torch_ops.cpp) against the ctypes binding of the same C ABI:
 the same kernels behind both, so results must be bit-identical; plus a tiny UNet forward with the torch-op backend."""
+import os
+
 import pytest
 import torch
 
@@ -84,7 +86,15 @@ def test_torch_ops_match_ctypes_binding_bitwise(both):
     wqkv, bqkv = rnd(960, 320, seed=23, scale=0.05), rnd(960, seed=24, dtype=torch.float32)
     wo, bo = rnd(320, 320, seed=25, scale=0.05), rnd(320, seed=26, dtype=torch.float32)
     kwt = dict(b=2, t=16, hw=40, heads=5, ln_eps=1e-5)
-    assert torch.equal(t.temporal_attn_fused(x0, wqkv, bqkv, wo, bo, **kwt), c.temporal_attn_fused(x0, wqkv, bqkv, wo, bo, **kwt))
+    os.environ["TC_TB_FUSED"] = "1"                  # the level-0 single launch is opt-in since round 6 (the library reads the switch per call)
+    try:
+        assert torch.equal(t.temporal_attn_fused(x0, wqkv, bqkv, wo, bo, **kwt), c.temporal_attn_fused(x0, wqkv, bqkv, wo, bo, **kwt))
+    finally:
+        os.environ.pop("TC_TB_FUSED", None)
+    # ABI 13: the default route of every temporal self-attention
+    kwq = dict(b=2, t=16, hw=40, heads=5)
+    assert torch.equal(t.temporal_qkv_attn(x0, wqkv, None, **kwq), c.temporal_qkv_attn(x0, wqkv, None, **kwq))
+    assert torch.equal(t.temporal_qkv_attn(x0, wqkv, bqkv, **kwq), c.temporal_qkv_attn(x0, wqkv, bqkv, **kwq))
 
 
 def test_tiny_unet_through_torch_op_layer(both, tiny_sd):
