@@ -65,11 +65,15 @@ class EmuOps:
     def temporal_qkv_attn_eligible(self, *, b, t, hw, c, heads, ldx=None):
         return bool(self.tqa) and t == 16 and heads * 64 == c and hw % 8 == 0
 
-    def temporal_qkv_attn(self, x, wqkv, bqkv=None, *, b, t, hw, heads, scale=None):
+    def temporal_qkv_attn(self, x, wqkv, bqkv=None, *, b, t, hw, heads, scale=None, out=None):
         """csrc/qkv_attn.hip: the roundings of the two launches it replaces (q / k / v and the attention output in bf16, fp32
         sums; its softmax weights are bf16 where tc_attn_temporal keeps fp32 -- inside the operator bound)."""
         self.tqa_calls += 1
-        return self.attention_temporal(self.gemm(x, wqkv, bqkv), b=b, t=t, hw=hw, heads=heads, scale=scale)
+        y = self.attention_temporal(self.gemm(x, wqkv, bqkv), b=b, t=t, hw=hw, heads=heads, scale=scale)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
 
     def _out(self, x, f32=False):
         if f32:

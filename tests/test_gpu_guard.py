@@ -212,6 +212,24 @@ def test_guard_attention_temporal(hip, emu, b, t, hw, heads):
           emu.attention_temporal(qkv, b=b, t=t, hw=hw, heads=heads), "guard temporal attention")
 
 
+@pytest.mark.parametrize("b,hw,c,bias", [(1, 8, 64, False), (1, 8, 128, True), (2, 16, 64, True), (1, 24, 320, False)])
+def test_guard_temporal_qkv_attn(hip, emu, b, hw, c, bias):
+    """ABI 13 (csrc/qkv_attn.hip): the projection's input rows, the fused weight, the optional bias and the RESULT each end flush
+    with their own region -- the gathered row loads (a pixel's 16 frames are hw rows apart), the three weight blocks of a head and
+    the per-wave 128-byte row stores touch nothing beyond them.  Also at a wider output pitch (the last column block of a buffer)."""
+    heads = c // 64
+    x, w = rnd(b * 16 * hw, c, seed=50), rnd(3 * c, c, seed=51, scale=c ** -0.5)
+    bq = rnd(3 * c, seed=52, dtype=torch.float32) if bias else None
+    kw = dict(b=b, t=16, hw=hw, heads=heads)
+    out = gout((b * 16 * hw, c))
+    hip.temporal_qkv_attn(x, w, bq, out=out, **kw)
+    close(out, emu.temporal_qkv_attn(x, w, bq, **kw), "guard temporal qkv + attention")
+    wide = gout((b * 16 * hw, 2 * c))
+    hip.temporal_qkv_attn(x, w, bq, out=wide[:, c:], **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(wide[:, c:], out) and float(wide[:, :c].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("samples,rows,c", [(1, 1, 64), (3, 1, 64), (4, 4, 64), (2, 7, 320), (5, 3, 2560), (1, 13, 960)])
 def test_guard_groupnorm(hip, emu, samples, rows, c):
     x = rnd(samples * rows, c, seed=25)

@@ -343,7 +343,7 @@ class HipOps:
         p = self._tqa_params(b, t, hw, c, heads, c if ldx is None else ldx, c, None)
         return bool(self.lib.tc_temporal_qkv_attn_eligible(C.byref(p)))
 
-    def temporal_qkv_attn(self, x, wqkv, bqkv=None, *, b, t, hw, heads, scale=None):
+    def temporal_qkv_attn(self, x, wqkv, bqkv=None, *, b, t, hw, heads, scale=None, out=None):
         """Attn_frames(x . wqkv^T + bqkv) -> [rows, c] as ONE launch: `gemm(x, wqkv, bqkv)` + `attention_temporal` without the
         [rows, 3c] tensor between them (reference attention.py:96-134 over the frames of a pixel, TemporalTransformer
         attention.py:365-412).  x: the projection's input (LayerNorm output) rows; the result feeds to_out."""
@@ -355,8 +355,13 @@ class HipOps:
         if x.stride(1) != 1 or m != b * t * hw or tuple(wqkv.shape) != (3 * c, c) or c != heads * 64 \
                 or (bqkv is not None and bqkv.numel() != 3 * c):
             raise ValueError("temporal_qkv_attn: x [b*t*hw, c] rows, wqkv [3c, c], bqkv [3c] or None, c = heads * 64")
-        out = torch.empty((m, c), dtype=BF16, device=x.device)
-        p = self._tqa_params(b, t, hw, c, heads, x.stride(0), c, scale)
+        if out is None:
+            out = torch.empty((m, c), dtype=BF16, device=x.device)
+        elif tuple(out.shape) != (m, c) or out.stride(1) != 1:
+            raise ValueError("temporal_qkv_attn: out must be [b*t*hw, c] rows")
+        else:
+            _dev(out, BF16, "temporal_qkv_attn out", contiguous=False)
+        p = self._tqa_params(b, t, hw, c, heads, x.stride(0), out.stride(0), scale)
         p.x, p.wqkv, p.bqkv, p.out = x.data_ptr(), wqkv.data_ptr(), (None if bqkv is None else bqkv.data_ptr()), out.data_ptr()
         _lib.check(self.lib.tc_temporal_qkv_attn(C.byref(p), _stream()), "tc_temporal_qkv_attn")
         return out

@@ -91,7 +91,9 @@ class TorchLibOps(HipOps):
         return self.t.temporal_attn_fused(x, wqkv, bqkv, wo, bo, int(b), int(t), int(hw), int(heads),
                                           -1.0 if ln_eps is None else float(ln_eps), float(64 ** -0.5 if scale is None else scale))
 
-    def temporal_qkv_attn(self, x, wqkv, bqkv=None, *, b, t, hw, heads, scale=None):
+    def temporal_qkv_attn(self, x, wqkv, bqkv=None, *, b, t, hw, heads, scale=None, out=None):
+        if out is not None:                                  # an explicit result buffer: the ctypes method (the op schema is functional)
+            return super().temporal_qkv_attn(x, wqkv, bqkv, b=b, t=t, hw=hw, heads=heads, scale=scale, out=out)
         return self.t.temporal_qkv_attn(x, wqkv, bqkv, int(b), int(t), int(hw), int(heads), float(64 ** -0.5 if scale is None else scale))
 
     def groupnorm(self, x, gamma, beta, *, samples, rows, eps, silu=False, part=None, prefetch=None, prefetch_linear=False):
