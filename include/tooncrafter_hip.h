@@ -187,7 +187,8 @@ int tc_temporal_attn_fused(const TcTbParams* p, void* stream);
  *     out[:, h*64 .. h*64+63] = Attn_frames(x . wqkv[q_h | k_h | v_h]^T + bqkv),     every head h
  * i.e. tc_gemm_bf16(x, wqkv) followed by tc_attn_temporal, without the [rows, 3c] tensor between them reaching HBM.
  * `out` is what to_out (a tc_gemm_bf16 with bias and residual) takes next.  t = 16, c = heads * 64, hw % 8 == 0
- * (tc_temporal_qkv_attn_eligible); UNet levels 1-3 (c = 640 / 1280) -- level 0 has tc_temporal_attn_fused.
+ * (tc_temporal_qkv_attn_eligible): every level of the UNet (c = 320 ... 1280; since round 6 level 0 takes LayerNorm -> this ->
+ * to_out by default, tc_temporal_attn_fused only with TC_TB_FUSED=1).
  *   x     [b*t*hw, ldx] bf16, row = (batch * t + frame) * hw + pixel: the projection's input (the LayerNorm's output);
  *   wqkv  [3*c, c] bf16: rows [0, c) = to_q, [c, 2c) = to_k, [2c, 3c) = to_v (head h at h*64) -- tc_gemm_bf16's operand;
  *   bqkv  [3*c] fp32 or NULL (the reference's projections have no bias);   out [b*t*hw, ldo] bf16;   scale = 64^-0.5. */
