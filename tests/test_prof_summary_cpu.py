@@ -32,6 +32,8 @@ def _db(path):
         add("(anonymous namespace)::ddim_apply_kernel(TcDdimParams, double const*)", 10)
     add("Cijk_Ailk_Bljk_BBS_BH_MT256x256x64", 900)                                                   # calibration, inside the window
     add("void (anonymous namespace)::gemm_wide_kernel<1, 4, false>(TcGemmParams, int)", 1000)          # a decode
+    add("(anonymous namespace)::video_to_u8_kernel(float const*, unsigned char*, int, long)", 5)      # the clip's last kernel
+    add("void (anonymous namespace)::gemm_kernel<1, 2, 2, true>(TcGemmParams, int, int, int)", 400)    # the encoder pass bench.py times afterwards
     add("void at::native::vectorized_elementwise_kernel<4, at::native::FillFunctor<float>>(...)", 3)  # an extra, after the window
     c.executemany("insert into kernels values (?,?,?,?,?,?,?)", rows)
     c.commit()
@@ -53,10 +55,14 @@ def test_tables_and_fraction(tmp_path):
     assert "Cijk_" not in table and "FillFunctor" not in table
     assert "distribution_elementwise" in table                      # the sampler's own randn inside the window stays
     # GEMM family: 4 x (600 + 300 + 100) us + 1000 us = 5.0 ms for 4 x 22.661 + 57.32 TFLOP
-    fam_ms = 5.0
+    fam_ms = 5.4
     tf = (4 * 22.661 + 57.32) / (fam_ms / 1e3)
     line = [ln for ln in out.splitlines() if ln.startswith("# GEMM family")][0]
-    assert "13 launches" in line and f"{fam_ms:.1f} ms" in line and f"{tf:.0f} TF/s" in line and f"{tf / 2500.0:.3f} of the" in line
+    assert "14 launches" in line and f"{fam_ms:.1f} ms" in line and f"{tf:.0f} TF/s" in line and f"{tf / 2500.0:.3f} of the" in line
     # per step: 2 usable intervals between ddim_apply marks (the first is skipped), 1.0 ms of GEMM family each
     step = [ln for ln in out.splitlines() if ln.startswith("# per DDIM step")][0]
     assert "(2 steps" in step and "GEMM family 1.00 ms" in step
+    # the clip as bench.py composes it: 50 x the 1.00-ms step + the decode behind the last step (1 launch, 1.0 ms)
+    clip = [ln for ln in out.splitlines() if ln.startswith("# GEMM family, one clip")][0]
+    tfc = (50 * 22.661 + 57.32) / (51.0 / 1e3)
+    assert "in 51.0 ms" in clip and f"{tfc:.0f} TF/s" in clip and f"{tfc / 2500.0:.3f} of peak" in clip
