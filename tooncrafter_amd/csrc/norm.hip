@@ -232,6 +232,11 @@ __global__ __launch_bounds__(256) void gn_finalize_part_kernel(const float* __re
   }
 }
 
+// (Round 6: the finalize launch folded into THIS kernel's prologue -- every apply block reduces its sample's partial sums itself,
+// thread (pair, quarter) over chunks quarter, quarter + 4, ... in fp64, fixed order: bit-identical to the three-launch form on
+// every shape tried -- removes 94 of a forward's 923 launches and LOSES 2.4 % per guided forward (35.27 -> 36.15 ms; the decoder's
+// norms 10.0 -> 10.7 ms): up to 64 KB of partials read and reduced by each of ~512 blocks costs twice the 4.6 us launch it
+// saves.  profiles/r06_gn_finalize_in_apply_forward_ab.txt.  Removed; round 1 had measured the same idea "neutral".)
 // SILU is a template parameter: as a run-time flag every element paid for the activation AND a select
 template <bool SILU>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
