@@ -45,6 +45,7 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -377,17 +378,20 @@ int tc_conv_halo_try(const TcGemmParams& p, int batch, hipStream_t s, bool dry) 
   if (p.gather != TC_GATHER_CONV3x3 && p.gather != TC_GATHER_CONVT3) return 0;
   if (mode == 1) {
     // a switch that selects among the IMPLICIT-GEMM kernels names the kernel under test / under measurement: keep out of its way
-    // (... and say so, once: an A/B script that exports one of them for ANOTHER reason also moves every 3x3 convolution to a
-    // different kernel, and a silent move is a confounded comparison -- ADVICE r5)
-    for (const char* sw : {"TC_GEMM_TILE16", "TC_GEMM8", "TC_GEMM_PIPE", "TC_GEMM_SPLITK", "TC_GEMM_WS", "TC_G16_ILV", "TC_G16_TALL",
-                           "TC_GEMM_WIDE", "TC_GEMM_ORDER", "TC_GEMM_NMAJOR"}) {
-      const char* e = getenv(sw);
-      if (e && e[0]) {
+    // -- but only when it actually FORCES something, i.e. carries a value other than its default (an A/B script that
+    // exports `TC_GEMM8=1` for one arm had every 3x3 convolution moved to another kernel in BOTH arms, silently -- round 6's
+    // switch sweep ran into exactly that), and say so, once, when it happens
+    struct Sw { const char* name; const char* dflt; };            // dflt == nullptr: any value forces
+    static const Sw sws[] = {{"TC_GEMM_TILE16", "1"}, {"TC_GEMM8", "1"}, {"TC_GEMM_PIPE", "1"}, {"TC_GEMM_SPLITK", nullptr}, {"TC_GEMM_WS", "1"},
+                             {"TC_G16_ILV", nullptr}, {"TC_G16_TALL", "0"}, {"TC_GEMM_WIDE", "1"}, {"TC_GEMM_ORDER", "8"}, {"TC_GEMM_NMAJOR", "1"}};
+    for (const Sw& sw : sws) {
+      const char* e = getenv(sw.name);
+      if (e && e[0] && !(sw.dflt && strcmp(e, sw.dflt) == 0)) {
         static bool said = false;
         if (!said && !dry) {
           said = true;
           fprintf(stderr, "[tooncrafter_hip] %s=%s is set: the 3x3 convolutions stay on the implicit-GEMM kernels "
-                          "(halo-patch route suppressed; TC_CONV_HALO=2 forces it)\n", sw, e);
+                          "(halo-patch route suppressed; TC_CONV_HALO=2 forces it)\n", sw.name, e);
         }
         return 0;
       }
